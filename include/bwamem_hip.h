@@ -1,0 +1,205 @@
+/*
+ * bwamem_hip.h -- C-ABI of libbwamem_hip.so: BWA-MEM's seed-extension hot
+ * path (banded affine-gap DP) on AMD Instinct MI355X (gfx950).
+ *
+ * This is the drop-in boundary for the path named in BASELINE.json
+ * (SURVEY.md §8b).  Plain C: pointers, sizes, fixed-width integers; no C++,
+ * HIP or torch types appear in any signature.  Citations are relative to the
+ * reference tree (peterpengwei/bwa-mem-quickassist, bwa-0.7.8/).
+ *
+ * Three levels, lowest first:
+ *
+ *   L2  batch DP         bmh_extend_batch*   replaces N calls of ksw_extend2 (ksw.h:108, ksw.c:379-476)
+ *                        bmh_global_batch*   replaces N calls of ksw_global2 (ksw.h:84,  ksw.c:501-584)
+ *   L2' per-call drop-in ksw_extend2 / ksw_global2 with the exact ksw.h signatures
+ *                        (libbwamem_hip_dropin.so; each call is a batch of one)
+ *   L3  extension driver bmh_chain2aln_batch and the fork's own seam
+ *                        mem_chain2aln_batched(...) (bwamem.c:580, call site bwamem.c:1110),
+ *                        which replace the per-read loop over mem_chain2aln (bwamem.c:730-878)
+ *                        inside mem_align1_core_batched (bwamem.c:1086-1120).
+ *
+ * Error convention: every function returns BMH_OK (0) or a negative
+ * BMH_E_* code; nothing is ever silently dropped.  The reference has no error
+ * returns on this path (assert/exit: bwamem.c:758,845,1184; malloc_wrap.c:14-19),
+ * so the integration stub in INTEGRATION.md aborts on a negative code.
+ * There is NO CPU fallback inside this library: without a usable GPU every
+ * compute entry point fails with BMH_E_NODEVICE.
+ */
+#ifndef BWAMEM_HIP_H
+#define BWAMEM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BMH_VERSION 100 /* 0.1.0 */
+
+enum {
+	BMH_OK = 0,
+	BMH_E_NODEVICE = -1, /* no HIP device / HIP runtime error at init        */
+	BMH_E_HIP = -2,      /* a HIP call failed; see bmh_last_error()           */
+	BMH_E_ARG = -3,      /* invalid argument (NULL, negative size, ...)       */
+	BMH_E_RANGE = -4,    /* a task is outside the supported range (see below) */
+	BMH_E_NOMEM = -5,    /* host or device allocation failed                  */
+	BMH_E_CIGAR_CAP = -6 /* a global task produced more CIGAR ops than its cap */
+};
+
+/* ---- scoring / band parameters: the hot-path fields of mem_opt_t
+ * (bwamem.h:21-48; defaults bwamem.c:45-75; matrix bwa.c:77-86). Constant for a run. */
+typedef struct bmh_params {
+	int32_t o_del, e_del, o_ins, e_ins; /* bwamem.h:23-24                             */
+	int32_t zdrop;                      /* bwamem.h:28 ; <=0 disables (ksw.c:455)      */
+	int32_t a;                          /* match score; only the L3 driver reads it    */
+	int32_t w;                          /* opt->w;       only the L3 driver reads it    */
+	int32_t pen_clip5, pen_clip3;       /* bwamem.h:26;  only the L3 driver reads it    */
+	int8_t mat[25];                     /* bwamem.h:47 ; m = 5                           */
+	int8_t pad_[3];
+} bmh_params_t;
+
+/* ---- one ksw_extend2 call (ksw.c:379).  32 bytes.
+ * Sequences are base codes 0..4, one byte per base, living in a byte pool.
+ * With BMH_F_QREV / BMH_F_TREV the sequence is read backwards from the offset:
+ * base k = pool[off - k].  That is how the left extension's reversed copies
+ * (bwamem.c:813-817) are expressed without materialising them. */
+#define BMH_F_QREV 1u
+#define BMH_F_TREV 2u
+typedef struct bmh_ext_task {
+	uint64_t q_off;    /* pool offset of query base 0                     */
+	uint64_t t_off;    /* pool offset of target base 0                    */
+	uint16_t qlen;     /* ksw_extend2 arg 1                               */
+	uint16_t tlen;     /* arg 3                                           */
+	int32_t h0;        /* arg 14                                          */
+	int16_t w;         /* arg 11 (before the clamp of ksw.c:398-406)      */
+	int16_t end_bonus; /* arg 12                                          */
+	uint16_t flags;    /* BMH_F_*                                         */
+	uint16_t rsv_;
+} bmh_ext_task_t;
+
+/* ---- what ksw_extend2 returns (ksw.c:470-475).  24 bytes. */
+typedef struct bmh_ext_result {
+	int32_t score, qle, tle, gtle, gscore, max_off;
+} bmh_ext_result_t;
+
+/* ---- one ksw_global2 call (ksw.c:501).  32 bytes. */
+typedef struct bmh_glb_task {
+	uint64_t q_off, t_off;
+	uint16_t qlen, tlen;
+	int32_t w;          /* arg 11                                                   */
+	uint32_t cigar_off; /* first uint32 slot of this task in the CIGAR output pool   */
+	uint32_t cigar_cap; /* slots reserved; 0 = score only (cigar_==NULL, ksw.c:566)  */
+} bmh_glb_task_t;
+
+typedef struct bmh_glb_result {
+	int32_t score;   /* return value, ksw.c:565                                  */
+	int32_t n_cigar; /* *n_cigar_; if > cigar_cap the CIGAR was NOT fully written */
+} bmh_glb_result_t;
+
+/* Supported range (checked on the host, BMH_E_RANGE otherwise):
+ *   extend: 0 <= qlen,tlen <= 65535; scores must fit int16 lanes:
+ *           h0 + qlen*max(mat) <= 32000; o_ins >= 0 (SURVEY.md §7 hard part 1).
+ *   global: qlen,tlen <= 65535. */
+
+typedef struct bmh_ctx bmh_ctx_t;
+
+int bmh_version(void);
+const char *bmh_strerror(int code);
+const char *bmh_last_error(const bmh_ctx_t *ctx); /* text of the last failing HIP call */
+
+int bmh_device_count(int *n);
+/* One context = one GPU + one HIP stream + grow-only device/pinned workspaces.
+ * A context is used by one host thread at a time. */
+int bmh_ctx_create(bmh_ctx_t **ctx, int device);
+int bmh_ctx_destroy(bmh_ctx_t *ctx);
+int bmh_ctx_set_params(bmh_ctx_t *ctx, const bmh_params_t *p);
+/* Run on a caller-owned hipStream_t (passed as void*); NULL restores the context's own. */
+int bmh_ctx_set_stream(bmh_ctx_t *ctx, void *hip_stream);
+int bmh_ctx_sync(bmh_ctx_t *ctx);
+
+/* ---- L2, host buffers: H2D copy, launch, D2H copy, synchronous on return. */
+int bmh_extend_batch(bmh_ctx_t *ctx, const uint8_t *seqpool, size_t pool_bytes,
+                     const bmh_ext_task_t *tasks, int64_t n, bmh_ext_result_t *results);
+int bmh_global_batch(bmh_ctx_t *ctx, const uint8_t *seqpool, size_t pool_bytes,
+                     const bmh_glb_task_t *tasks, int64_t n, bmh_glb_result_t *results,
+                     uint32_t *cigar_pool, size_t cigar_pool_words);
+
+/* ---- L2, device-resident buffers: asynchronous on the context's stream.
+ * `d_order` (nullable) is a device array of n task indices giving the launch
+ * order (e.g. sorted by length for tail balance); results stay at task index. */
+int bmh_extend_batch_device(bmh_ctx_t *ctx, const uint8_t *d_seqpool,
+                            const bmh_ext_task_t *d_tasks, int64_t n,
+                            bmh_ext_result_t *d_results, const uint32_t *d_order);
+int bmh_global_batch_device(bmh_ctx_t *ctx, const uint8_t *d_seqpool,
+                            const bmh_glb_task_t *d_tasks, int64_t n,
+                            bmh_glb_result_t *d_results, uint32_t *d_cigar_pool,
+                            const uint32_t *d_order);
+
+/* ---- static shard of one host batch over several contexts (one per GPU,
+ * SURVEY.md §8e): contiguous split, one stream per device, no collective. */
+int bmh_extend_batch_sharded(bmh_ctx_t *const *ctxs, int n_ctx, const uint8_t *seqpool,
+                             size_t pool_bytes, const bmh_ext_task_t *tasks, int64_t n,
+                             bmh_ext_result_t *results);
+
+/* ---- kernel timing: HIP events recorded on the context's stream around the
+ * dominant kernel of the last *_device call.  ms < 0 if none. */
+int bmh_last_kernel_ms(bmh_ctx_t *ctx, float *ms);
+int bmh_set_kernel_timing(bmh_ctx_t *ctx, int enable);
+
+/* ---- L3: data carriers of the extension driver, layout-compatible with the
+ * reference so that its structs can be passed straight through. */
+typedef struct bmh_seed {  /* == mem_seed_t, bwamem.c:168-171 */
+	int64_t rbeg;
+	int32_t qbeg, len;
+} bmh_seed_t;
+
+typedef struct bmh_chain { /* == mem_chain_t, bwamem.c:173-177 */
+	int32_t n, m;
+	int64_t pos;
+	bmh_seed_t *seeds;
+} bmh_chain_t;
+
+typedef struct bmh_chain_v { /* == mem_chain_v, bwamem.c:179 */
+	size_t n, m;
+	bmh_chain_t *a;
+} bmh_chain_v;
+
+typedef struct bmh_alnreg { /* == mem_alnreg_t, bwamem.h:50-62 (64 bytes) */
+	int64_t rb, re;
+	int32_t qb, qe;
+	int32_t score, truesc, sub, csub, sub_n, w, seedcov, secondary;
+	uint64_t hash;
+} bmh_alnreg_t;
+
+typedef struct bmh_alnreg_v { /* == mem_alnreg_v, bwamem.h:64; a is malloc/realloc'd */
+	size_t n, m;
+	bmh_alnreg_t *a;
+} bmh_alnreg_v;
+
+typedef struct bmh_read { /* the two bseq1_t fields the driver reads (bwa.h:18-22) */
+	int32_t l_seq;
+	const uint8_t *seq; /* base codes 0..4 (after bwamem.c:1093-1094) */
+} bmh_read_t;
+
+/* Replaces, for `n_reads` reads at once, the loop
+ *     for each chain c of read r: mem_chain2aln(opt,l_pac,pac,l_seq,seq,c,&regs[r])
+ * (bwamem.c:1101-1107 / :1136-1143).  Regions are APPENDED to regs[r] (kv_pushp
+ * semantics, bwamem.c:804), so entries already there (e.g. from
+ * mem_chain2aln_short) take part in the containment test of bwamem.c:769-802.
+ * `skip` (nullable): skip[r][c] != 0 means chain c of read r was already
+ * handled (mem_chain2aln_short returned 0) and must not be extended. */
+int bmh_chain2aln_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n_reads,
+                        const bmh_read_t *reads, const bmh_chain_v *chains,
+                        const uint8_t *const *skip, bmh_alnreg_v *regs);
+
+/* Counters of the last bmh_chain2aln_batch call (for the bench / logs). */
+typedef struct bmh_driver_stats {
+	int64_t rounds, ext_tasks, seeds_extended, seeds_skipped;
+} bmh_driver_stats_t;
+int bmh_driver_stats(const bmh_ctx_t *ctx, bmh_driver_stats_t *st);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

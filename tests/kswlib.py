@@ -1,0 +1,212 @@
+"""Shared test plumbing: record layouts, ctypes bindings of the CHECKERS.
+
+* oracle/liborc.so         -- our CPU restatement (always available; built on demand)
+* oracle/_ref/libksw_ref.so, libbwa_ref.so -- the reference compiled from
+  /root/reference by oracle/Makefile (only where that tree exists or the
+  prebuilt files travelled with the repo).
+
+Nothing in here is product code; the product is libbwamem_hip.so, bound in
+bwa-mem-quickassist_amd/__init__.py.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+REF_DIR = os.path.join(ORACLE_DIR, "_ref")
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+# ---- record layouts == include/bwamem_hip.h -------------------------------
+EXT_TASK = np.dtype([("q_off", "<u8"), ("t_off", "<u8"), ("qlen", "<u2"), ("tlen", "<u2"),
+                     ("h0", "<i4"), ("w", "<i2"), ("end_bonus", "<i2"), ("flags", "<u2"),
+                     ("rsv", "<u2")])
+EXT_RES = np.dtype([("score", "<i4"), ("qle", "<i4"), ("tle", "<i4"), ("gtle", "<i4"),
+                    ("gscore", "<i4"), ("max_off", "<i4")])
+GLB_TASK = np.dtype([("q_off", "<u8"), ("t_off", "<u8"), ("qlen", "<u2"), ("tlen", "<u2"),
+                     ("w", "<i4"), ("cigar_off", "<u4"), ("cigar_cap", "<u4")])
+GLB_RES = np.dtype([("score", "<i4"), ("n_cigar", "<i4")])
+PARAMS = np.dtype([("o_del", "<i4"), ("e_del", "<i4"), ("o_ins", "<i4"), ("e_ins", "<i4"),
+                   ("zdrop", "<i4"), ("a", "<i4"), ("w", "<i4"), ("pen_clip5", "<i4"),
+                   ("pen_clip3", "<i4"), ("mat", "i1", (25,)), ("pad", "i1", (3,))])
+SEED = np.dtype([("rbeg", "<i8"), ("qbeg", "<i4"), ("len", "<i4")])
+ALNREG = np.dtype([("rb", "<i8"), ("re", "<i8"), ("qb", "<i4"), ("qe", "<i4"), ("score", "<i4"),
+                   ("truesc", "<i4"), ("sub", "<i4"), ("csub", "<i4"), ("sub_n", "<i4"),
+                   ("w", "<i4"), ("seedcov", "<i4"), ("secondary", "<i4"), ("hash", "<u8")])
+assert EXT_TASK.itemsize == 32 and EXT_RES.itemsize == 24
+assert GLB_TASK.itemsize == 32 and GLB_RES.itemsize == 8
+assert PARAMS.itemsize == 64 and SEED.itemsize == 16 and ALNREG.itemsize == 64
+
+BMH_F_QREV, BMH_F_TREV = 1, 2
+
+
+def fill_scmat(a, b, n_score=-1):
+    """bwa_fill_scmat, reference bwa.c:77-86: diag a, off-diag -b, row/col 4 = -1."""
+    m = np.full((5, 5), -b, dtype=np.int8)
+    for i in range(4):
+        m[i, i] = a
+    m[4, :] = n_score
+    m[:, 4] = n_score
+    return m.reshape(25)
+
+
+def make_params(a=1, b=4, o_del=6, e_del=1, o_ins=6, e_ins=1, w=100, zdrop=100,
+                pen_clip5=5, pen_clip3=5, mat=None):
+    """Defaults = mem_opt_init, reference bwamem.c:45-75."""
+    p = np.zeros((), dtype=PARAMS)
+    p["a"], p["o_del"], p["e_del"], p["o_ins"], p["e_ins"] = a, o_del, e_del, o_ins, e_ins
+    p["w"], p["zdrop"], p["pen_clip5"], p["pen_clip3"] = w, zdrop, pen_clip5, pen_clip3
+    p["mat"] = fill_scmat(a, b) if mat is None else np.asarray(mat, dtype=np.int8)
+    return p
+
+
+# ---- ctypes mirrors ---------------------------------------------------------
+class OrcScoring(C.Structure):
+    _fields_ = [("o_del", C.c_int), ("e_del", C.c_int), ("o_ins", C.c_int), ("e_ins", C.c_int),
+                ("zdrop", C.c_int), ("m", C.c_int), ("mat", C.POINTER(C.c_int8))]
+
+
+class OrcExtOut(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("score", "qle", "tle", "gtle", "gscore", "max_off")]
+
+
+def _make(target=None):
+    cmd = ["make", "-s", "-C", ORACLE_DIR] + ([target] if target else [])
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL)
+
+
+_orc = None
+
+
+def load_oracle():
+    global _orc
+    if _orc is None:
+        path = os.path.join(ORACLE_DIR, "liborc.so")
+        srcs = [os.path.join(ORACLE_DIR, f) for f in ("ksw_oracle.c", "chain2aln_oracle.c",
+                                                      "ksw_oracle.h", "chain2aln_oracle.h")]
+        if not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in srcs):
+            _make("liborc.so")
+        lib = C.CDLL(path)
+        lib.orc_extend.restype = None
+        lib.orc_global.restype = C.c_int
+        lib.orc_extend_batch.restype = C.c_int
+        lib.orc_chain2aln.restype = None
+        lib.orc_get_seq.restype = C.c_void_p
+        lib.orc_cal_max_gap.restype = C.c_int
+        _orc = lib
+    return _orc
+
+
+def have_ref():
+    return os.path.exists(os.path.join(REF_DIR, "libksw_ref.so"))
+
+
+_ref_ksw = None
+
+
+def load_ref_ksw():
+    """The reference's own ksw.c compiled by oracle/Makefile (None if absent)."""
+    global _ref_ksw
+    if _ref_ksw is None and have_ref():
+        lib = C.CDLL(os.path.join(REF_DIR, "libksw_ref.so"))
+        lib.ksw_extend2.restype = C.c_int
+        lib.ksw_global2.restype = C.c_int
+        _ref_ksw = lib
+    return _ref_ksw
+
+
+def _u8p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_uint8))
+
+
+def scoring_of(p, keep):
+    mat = np.ascontiguousarray(p["mat"], dtype=np.int8)
+    keep.append(mat)
+    return OrcScoring(int(p["o_del"]), int(p["e_del"]), int(p["o_ins"]), int(p["e_ins"]),
+                      int(p["zdrop"]), 5, mat.ctypes.data_as(C.POINTER(C.c_int8)))
+
+
+def task_seqs(pool, t):
+    """Materialise (query, target) of one EXT_TASK/GLB_TASK honouring the REV flags."""
+    def get(off, n, rev):
+        off, n = int(off), int(n)
+        if rev:
+            return np.ascontiguousarray(pool[off - n + 1: off + 1][::-1]) if n else np.zeros(0, np.uint8)
+        return np.ascontiguousarray(pool[off: off + n])
+    flags = int(t["flags"]) if "flags" in t.dtype.names else 0
+    return get(t["q_off"], t["qlen"], flags & BMH_F_QREV), get(t["t_off"], t["tlen"], flags & BMH_F_TREV)
+
+
+def ref_extend_batch(p, pool, tasks):
+    """Run the compiled REFERENCE ksw_extend2 on every task."""
+    lib = load_ref_ksw()
+    out = np.zeros(len(tasks), dtype=EXT_RES)
+    mat = np.ascontiguousarray(p["mat"], dtype=np.int8)
+    ints = [C.c_int() for _ in range(5)]
+    for k, t in enumerate(tasks):
+        q, tg = task_seqs(pool, t)
+        sc = lib.ksw_extend2(int(t["qlen"]), _u8p(q), int(t["tlen"]), _u8p(tg), 5,
+                             mat.ctypes.data_as(C.POINTER(C.c_int8)), int(p["o_del"]), int(p["e_del"]),
+                             int(p["o_ins"]), int(p["e_ins"]), int(t["w"]), int(t["end_bonus"]),
+                             int(p["zdrop"]), int(t["h0"]), *[C.byref(x) for x in ints])
+        out[k] = (sc,) + tuple(x.value for x in ints)
+    return out
+
+
+def orc_extend_batch(p, pool, tasks, nthreads=1):
+    """Run OUR restatement on every task; returns (results, total_cells)."""
+    lib = load_oracle()
+    keep = []
+    sc = scoring_of(p, keep)
+    tasks = np.ascontiguousarray(tasks)
+    pool = np.ascontiguousarray(pool)
+    out = np.zeros(len(tasks), dtype=EXT_RES)
+    cells = C.c_int64(0)
+    lib.orc_extend_batch(C.byref(sc), pool.ctypes.data_as(C.c_void_p), tasks.ctypes.data_as(C.c_void_p),
+                         C.c_int(len(tasks)), out.ctypes.data_as(C.c_void_p), C.byref(cells),
+                         C.c_int(nthreads))
+    return out, cells.value
+
+
+def _global_generic(fn_call, pool, tasks):
+    res = np.zeros(len(tasks), dtype=GLB_RES)
+    cigars = []
+    for k, t in enumerate(tasks):
+        q, tg = task_seqs(pool, t)
+        n = C.c_int(0)
+        cg = C.POINTER(C.c_uint32)()
+        want = int(t["cigar_cap"]) > 0
+        sc = fn_call(int(t["qlen"]), _u8p(q), int(t["tlen"]), _u8p(tg), int(t["w"]),
+                     C.byref(n) if want else None, C.byref(cg) if want else None)
+        arr = np.array([cg[i] for i in range(n.value)], dtype=np.uint32)
+        if want and n.value:
+            _libc.free(cg)
+        res[k] = (sc, n.value)
+        cigars.append(arr)
+    return res, cigars
+
+
+_libc = C.CDLL(None)
+_libc.free.argtypes = [C.c_void_p]
+
+
+def ref_global_batch(p, pool, tasks):
+    lib = load_ref_ksw()
+    mat = np.ascontiguousarray(p["mat"], dtype=np.int8)
+
+    def call(ql, q, tl, t, w, n, cg):
+        return lib.ksw_global2(ql, q, tl, t, 5, mat.ctypes.data_as(C.POINTER(C.c_int8)), int(p["o_del"]),
+                               int(p["e_del"]), int(p["o_ins"]), int(p["e_ins"]), w, n, cg)
+    return _global_generic(call, pool, tasks)
+
+
+def orc_global_batch(p, pool, tasks):
+    lib = load_oracle()
+    keep = []
+    sc = scoring_of(p, keep)
+
+    def call(ql, q, tl, t, w, n, cg):
+        return lib.orc_global(C.byref(sc), ql, q, tl, t, w, n, cg)
+    return _global_generic(call, pool, tasks)
