@@ -1,0 +1,252 @@
+"""bwa-mem-quickassist_amd -- ctypes binding of libbwamem_hip.so (include/bwamem_hip.h).
+
+The product is the C-ABI shared library built from csrc/ (HIP kernels for gfx950) and
+host/ (the batched extension driver, plain C).  This module only loads it and gives the
+tests and bench.py a thin, numpy/torch-friendly view of the same entry points; it holds
+no algorithmic code and NO fallback: if the library is missing or no GPU is usable,
+every call raises.
+
+The directory name is fixed by the project layout and is not a valid Python identifier;
+load it with `__graft_entry__.load_package()` (importlib, module name
+`bwa_mem_quickassist_amd`).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbwamem_hip.so")
+DROPIN_PATH = os.path.join(_HERE, "libbwamem_hip_dropin.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "bwamem_hip.h")
+
+BMH_OK, BMH_E_NODEVICE, BMH_E_HIP, BMH_E_ARG, BMH_E_RANGE, BMH_E_NOMEM, BMH_E_CIGAR_CAP = 0, -1, -2, -3, -4, -5, -6
+BMH_F_QREV, BMH_F_TREV = 1, 2
+
+# record layouts == include/bwamem_hip.h
+EXT_TASK = np.dtype([("q_off", "<u8"), ("t_off", "<u8"), ("qlen", "<u2"), ("tlen", "<u2"),
+                     ("h0", "<i4"), ("w", "<i2"), ("end_bonus", "<i2"), ("flags", "<u2"),
+                     ("rsv", "<u2")])
+EXT_RES = np.dtype([("score", "<i4"), ("qle", "<i4"), ("tle", "<i4"), ("gtle", "<i4"),
+                    ("gscore", "<i4"), ("max_off", "<i4")])
+GLB_TASK = np.dtype([("q_off", "<u8"), ("t_off", "<u8"), ("qlen", "<u2"), ("tlen", "<u2"),
+                     ("w", "<i4"), ("cigar_off", "<u4"), ("cigar_cap", "<u4")])
+GLB_RES = np.dtype([("score", "<i4"), ("n_cigar", "<i4")])
+PARAMS = np.dtype([("o_del", "<i4"), ("e_del", "<i4"), ("o_ins", "<i4"), ("e_ins", "<i4"),
+                   ("zdrop", "<i4"), ("a", "<i4"), ("w", "<i4"), ("pen_clip5", "<i4"),
+                   ("pen_clip3", "<i4"), ("mat", "i1", (25,)), ("pad", "i1", (3,))])
+SEED = np.dtype([("rbeg", "<i8"), ("qbeg", "<i4"), ("len", "<i4")])
+ALNREG = np.dtype([("rb", "<i8"), ("re", "<i8"), ("qb", "<i4"), ("qe", "<i4"), ("score", "<i4"),
+                   ("truesc", "<i4"), ("sub", "<i4"), ("csub", "<i4"), ("sub_n", "<i4"),
+                   ("w", "<i4"), ("seedcov", "<i4"), ("secondary", "<i4"), ("hash", "<u8")])
+
+
+class BmhError(RuntimeError):
+    def __init__(self, code, detail=""):
+        self.code = code
+        super().__init__(f"libbwamem_hip error {code}: {detail}")
+
+
+class _Chain(C.Structure):
+    _fields_ = [("n", C.c_int32), ("m", C.c_int32), ("pos", C.c_int64), ("seeds", C.c_void_p)]
+
+
+class _ChainV(C.Structure):
+    _fields_ = [("n", C.c_size_t), ("m", C.c_size_t), ("a", C.POINTER(_Chain))]
+
+
+class _AlnregV(C.Structure):
+    _fields_ = [("n", C.c_size_t), ("m", C.c_size_t), ("a", C.c_void_p)]
+
+
+class _Read(C.Structure):
+    _fields_ = [("l_seq", C.c_int32), ("seq", C.c_void_p)]
+
+
+class _DriverStats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("rounds", "ext_tasks", "seeds_extended", "seeds_skipped")]
+
+
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library.  Raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise BmhError(BMH_E_NODEVICE, f"{LIB_PATH} not built; run __graft_entry__.build()")
+        L = C.CDLL(LIB_PATH)
+        L.bmh_strerror.restype = C.c_char_p
+        L.bmh_last_error.restype = C.c_char_p
+        L.bmh_last_error.argtypes = [C.c_void_p]
+        for name in ("bmh_ctx_destroy", "bmh_ctx_sync"):
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.bmh_ctx_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+        L.bmh_ctx_set_params.argtypes = [C.c_void_p, C.c_void_p]
+        L.bmh_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.bmh_ctx_set_qcap.argtypes = [C.c_void_p, C.c_int]
+        L.bmh_set_kernel_timing.argtypes = [C.c_void_p, C.c_int]
+        L.bmh_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.bmh_upload_pool.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.bmh_extend_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int64, C.c_void_p]
+        L.bmh_extend_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.bmh_extend_batch_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,
+                                               C.c_int64, C.c_void_p]
+        L.bmh_global_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int64, C.c_void_p,
+                                       C.c_void_p, C.c_size_t]
+        L.bmh_global_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                              C.c_void_p]
+        L.bmh_chain2aln_batch.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]
+        L.bmh_driver_stats.argtypes = [C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+_libc = C.CDLL(None)
+_libc.free.argtypes = [C.c_void_p]
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Context:
+    """One GPU + one stream (bmh_ctx_t).  Mirrors the C-ABI one to one."""
+
+    def __init__(self, device=0, params=None):
+        self._h = C.c_void_p()
+        rc = lib().bmh_ctx_create(C.byref(self._h), int(device))
+        if rc:
+            raise BmhError(rc, lib().bmh_strerror(rc).decode())
+        if params is not None:
+            self.set_params(params)
+
+    def _check(self, rc):
+        if rc:
+            raise BmhError(rc, f"{lib().bmh_strerror(rc).decode()}: {lib().bmh_last_error(self._h).decode()}")
+
+    def close(self):
+        if self._h:
+            lib().bmh_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_params(self, p):
+        p = np.ascontiguousarray(np.asarray(p, dtype=PARAMS).reshape(()))
+        self._check(lib().bmh_ctx_set_params(self._h, _ptr(p)))
+
+    def set_stream(self, hip_stream_ptr):
+        self._check(lib().bmh_ctx_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
+
+    def set_qcap(self, q):
+        self._check(lib().bmh_ctx_set_qcap(self._h, int(q)))
+
+    def sync(self):
+        self._check(lib().bmh_ctx_sync(self._h))
+
+    def set_kernel_timing(self, on=True):
+        self._check(lib().bmh_set_kernel_timing(self._h, 1 if on else 0))
+
+    def last_kernel_ms(self):
+        ms = C.c_float(-1)
+        self._check(lib().bmh_last_kernel_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    # ---- L2, host buffers
+    def extend_batch(self, pool, tasks):
+        """N x ksw_extend2 (reference ksw.c:379).  numpy in, numpy out."""
+        pool = np.ascontiguousarray(pool, dtype=np.uint8)
+        tasks = np.ascontiguousarray(tasks, dtype=EXT_TASK)
+        res = np.zeros(len(tasks), dtype=EXT_RES)
+        self._check(lib().bmh_extend_batch(self._h, _ptr(pool), pool.nbytes, _ptr(tasks), len(tasks), _ptr(res)))
+        return res
+
+    def global_batch(self, pool, tasks, cigar_words):
+        """N x ksw_global2 (reference ksw.c:501).  Returns (results, cigar_pool)."""
+        pool = np.ascontiguousarray(pool, dtype=np.uint8)
+        tasks = np.ascontiguousarray(tasks, dtype=GLB_TASK)
+        res = np.zeros(len(tasks), dtype=GLB_RES)
+        cig = np.zeros(max(int(cigar_words), 1), dtype=np.uint32)
+        self._check(lib().bmh_global_batch(self._h, _ptr(pool), pool.nbytes, _ptr(tasks), len(tasks), _ptr(res),
+                                           _ptr(cig), int(cigar_words)))
+        return res, cig
+
+    # ---- L2, device-resident (raw device pointers, e.g. torch tensors' data_ptr())
+    def extend_batch_device(self, d_pool, d_tasks, n, d_res, d_order=0):
+        self._check(lib().bmh_extend_batch_device(self._h, C.c_void_p(d_pool), C.c_void_p(d_tasks), int(n),
+                                                  C.c_void_p(d_res), C.c_void_p(d_order) if d_order else None))
+
+    def global_batch_device(self, d_pool, d_tasks, n, d_res, d_cigar, d_order=0):
+        self._check(lib().bmh_global_batch_device(self._h, C.c_void_p(d_pool), C.c_void_p(d_tasks), int(n),
+                                                  C.c_void_p(d_res), C.c_void_p(d_cigar),
+                                                  C.c_void_p(d_order) if d_order else None))
+
+    # ---- L3 driver
+    def chain2aln_batch(self, l_pac, pac, reads, chains):
+        """reads: list of uint8 code arrays; chains: per read a list of SEED arrays.
+        Returns per read an ALNREG array (what mem_chain2aln appends, reference bwamem.c:730-878)."""
+        n = len(reads)
+        pac = np.ascontiguousarray(pac, dtype=np.uint8)
+        keep = []
+        c_reads = (_Read * n)()
+        c_chv = (_ChainV * n)()
+        c_regs = (_AlnregV * n)()
+        for r in range(n):
+            seq = np.ascontiguousarray(reads[r], dtype=np.uint8)
+            keep.append(seq)
+            c_reads[r].l_seq, c_reads[r].seq = len(seq), seq.ctypes.data
+            arr = (_Chain * max(len(chains[r]), 1))()
+            for ci, seeds in enumerate(chains[r]):
+                sd = np.ascontiguousarray(seeds, dtype=SEED)
+                keep.append(sd)
+                arr[ci].n = arr[ci].m = len(sd)
+                arr[ci].pos = int(sd["rbeg"][0]) if len(sd) else 0
+                arr[ci].seeds = sd.ctypes.data
+            keep.append(arr)
+            c_chv[r].n = c_chv[r].m = len(chains[r])
+            c_chv[r].a = C.cast(arr, C.POINTER(_Chain))
+        rc = lib().bmh_chain2aln_batch(self._h, int(l_pac), _ptr(pac), n, C.cast(c_reads, C.c_void_p),
+                                       C.cast(c_chv, C.c_void_p), None, None, C.cast(c_regs, C.c_void_p))
+        out = []
+        for r in range(n):
+            k = c_regs[r].n
+            a = np.zeros(k, dtype=ALNREG)
+            if k:
+                C.memmove(a.ctypes.data, c_regs[r].a, k * ALNREG.itemsize)
+            if c_regs[r].a:
+                _libc.free(c_regs[r].a)
+            out.append(a)
+        self._check(rc)
+        return out
+
+    def driver_stats(self):
+        st = _DriverStats()
+        self._check(lib().bmh_driver_stats(self._h, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in _DriverStats._fields_}
+
+
+def extend_batch_sharded(ctxs, pool, tasks):
+    """Static contiguous shard of one host batch over several contexts (one per GPU)."""
+    pool = np.ascontiguousarray(pool, dtype=np.uint8)
+    tasks = np.ascontiguousarray(tasks, dtype=EXT_TASK)
+    res = np.zeros(len(tasks), dtype=EXT_RES)
+    arr = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    rc = lib().bmh_extend_batch_sharded(arr, len(ctxs), _ptr(pool), pool.nbytes, _ptr(tasks), len(tasks), _ptr(res))
+    if rc:
+        raise BmhError(rc, lib().bmh_strerror(rc).decode())
+    return res
+
+
+def declared_symbols():
+    """Every function name declared in include/bwamem_hip.h (for the symbol-export test)."""
+    import re
+    txt = open(HEADER_PATH).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(bmh_[a-z0-9_]+)\s*\(", txt)))

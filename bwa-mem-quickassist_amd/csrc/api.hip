@@ -1,0 +1,401 @@
+// api.hip -- the C-ABI of libbwamem_hip.so (include/bwamem_hip.h): contexts, parameter upload,
+// host-buffer and device-resident batch entry points, static multi-GPU sharding.
+// No CPU fallback lives here: if HIP is unusable every compute entry point returns an error.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#include "bmh_ctx.h"
+
+namespace bmh {
+
+int set_hip_error(bmh_ctx *ctx, hipError_t e, const char *what)
+{
+	if (ctx) {
+		ctx->last_error = std::string(what) + ": " + hipGetErrorString(e);
+	}
+	return BMH_E_HIP;
+}
+
+int ensure(bmh_ctx *ctx, DevBuf &b, size_t bytes)
+{
+	if (bytes <= b.cap) return BMH_OK;
+	size_t cap = std::max(bytes, b.cap + b.cap / 2);
+	cap = (cap + 255) & ~(size_t)255;
+	if (b.p) BMH_HIP(ctx, hipFree(b.p));
+	b.p = nullptr, b.cap = 0;
+	hipError_t e = hipMalloc(&b.p, cap);
+	if (e != hipSuccess) {
+		set_hip_error(ctx, e, "hipMalloc(workspace)");
+		return BMH_E_NOMEM;
+	}
+	b.cap = cap;
+	return BMH_OK;
+}
+
+static void free_buf(DevBuf &b)
+{
+	if (b.p) (void)hipFree(b.p);
+	b.p = nullptr, b.cap = 0;
+}
+
+// read-and-clear the device error flag; the stream must be idle
+static int fetch_err(bmh_ctx *ctx)
+{
+	BMH_HIP(ctx, hipMemcpyAsync(ctx->h_err, ctx->d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+	BMH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	int e = *ctx->h_err;
+	if (e != 0) {
+		BMH_HIP(ctx, hipMemsetAsync(ctx->d_err, 0, sizeof(int), ctx->stream));
+		BMH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		ctx->last_error = "a task was outside the supported range (see bwamem_hip.h)";
+	}
+	return e;
+}
+
+} // namespace bmh
+
+using namespace bmh;
+
+extern "C" {
+
+int bmh_version(void) { return BMH_VERSION; }
+
+const char *bmh_strerror(int code)
+{
+	switch (code) {
+	case BMH_OK: return "ok";
+	case BMH_E_NODEVICE: return "no usable HIP device";
+	case BMH_E_HIP: return "HIP runtime error";
+	case BMH_E_ARG: return "invalid argument";
+	case BMH_E_RANGE: return "task outside the supported range";
+	case BMH_E_NOMEM: return "out of memory";
+	case BMH_E_CIGAR_CAP: return "CIGAR longer than the reserved slot range";
+	default: return "unknown error";
+	}
+}
+
+const char *bmh_last_error(const bmh_ctx_t *ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+
+int bmh_device_count(int *n)
+{
+	int c = 0;
+	if (!n) return BMH_E_ARG;
+	if (hipGetDeviceCount(&c) != hipSuccess) {
+		*n = 0;
+		return BMH_E_NODEVICE;
+	}
+	*n = c;
+	return BMH_OK;
+}
+
+int bmh_ctx_create(bmh_ctx_t **out, int device)
+{
+	if (!out) return BMH_E_ARG;
+	*out = nullptr;
+	int c = 0;
+	if (hipGetDeviceCount(&c) != hipSuccess || c <= 0) return BMH_E_NODEVICE;
+	if (device < 0 || device >= c) return BMH_E_ARG;
+	bmh_ctx *ctx = new (std::nothrow) bmh_ctx();
+	if (!ctx) return BMH_E_NOMEM;
+	ctx->device = device;
+	hipError_t e;
+	if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess ||
+	    (e = hipMalloc((void **)&ctx->d_err, sizeof(int))) != hipSuccess || (e = hipMemset(ctx->d_err, 0, sizeof(int))) != hipSuccess ||
+	    (e = hipHostMalloc((void **)&ctx->h_err, sizeof(int), hipHostMallocDefault)) != hipSuccess ||
+	    (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess) {
+		fprintf(stderr, "[bwamem_hip] context creation failed: %s\n", hipGetErrorString(e));
+		bmh_ctx_destroy(ctx);
+		return BMH_E_NODEVICE;
+	}
+	ctx->stream = ctx->own_stream;
+	*out = ctx;
+	return BMH_OK;
+}
+
+int bmh_ctx_destroy(bmh_ctx_t *ctx)
+{
+	if (!ctx) return BMH_OK;
+	(void)hipSetDevice(ctx->device);
+	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+	free_buf(ctx->d_pool), free_buf(ctx->d_tasks), free_buf(ctx->d_res), free_buf(ctx->d_order);
+	free_buf(ctx->d_cigar), free_buf(ctx->d_scratch);
+	if (ctx->d_err) (void)hipFree(ctx->d_err);
+	if (ctx->h_err) (void)hipHostFree(ctx->h_err);
+	if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+	if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+	if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+	delete ctx;
+	return BMH_OK;
+}
+
+int bmh_ctx_set_params(bmh_ctx_t *ctx, const bmh_params_t *p)
+{
+	if (!ctx || !p) return BMH_E_ARG;
+	// e>=1: the reference divides by e (ksw.c:401,404); o_ins>=0: the scan form of F needs it
+	if (p->e_del < 1 || p->e_ins < 1 || p->o_ins < 0 || p->o_del < 0) {
+		ctx->last_error = "need e_del>=1, e_ins>=1, o_del>=0, o_ins>=0";
+		return BMH_E_RANGE;
+	}
+	ctx->params = *p;
+	DevParams &d = ctx->dev;
+	d.o_del = p->o_del, d.e_del = p->e_del, d.o_ins = p->o_ins, d.e_ins = p->e_ins, d.zdrop = p->zdrop;
+	d.max_mat = 0; // ksw.c:399-400 starts the maximum at 0
+	for (int i = 0; i < 25; ++i) d.max_mat = std::max(d.max_mat, (int)p->mat[i]);
+	uint8_t bytes[28] = {0};
+	memcpy(bytes, p->mat, 25);
+	memcpy(d.matw, bytes, 28);
+	ctx->have_params = true;
+	return BMH_OK;
+}
+
+int bmh_ctx_set_stream(bmh_ctx_t *ctx, void *s)
+{
+	if (!ctx) return BMH_E_ARG;
+	ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+	return BMH_OK;
+}
+
+int bmh_ctx_set_qcap(bmh_ctx_t *ctx, int qcap)
+{
+	if (!ctx || qcap < 1 || qcap > 65535) return BMH_E_ARG;
+	ctx->qcap = qcap;
+	return BMH_OK;
+}
+
+int bmh_ctx_sync(bmh_ctx_t *ctx)
+{
+	if (!ctx) return BMH_E_ARG;
+	BMH_HIP(ctx, hipSetDevice(ctx->device));
+	BMH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return fetch_err(ctx);
+}
+
+int bmh_set_kernel_timing(bmh_ctx_t *ctx, int enable)
+{
+	if (!ctx) return BMH_E_ARG;
+	ctx->timing = enable != 0;
+	ctx->ev_valid = false;
+	return BMH_OK;
+}
+
+int bmh_last_kernel_ms(bmh_ctx_t *ctx, float *ms)
+{
+	if (!ctx || !ms) return BMH_E_ARG;
+	*ms = -1.f;
+	if (!ctx->ev_valid) return BMH_OK;
+	BMH_HIP(ctx, hipEventSynchronize(ctx->ev1));
+	BMH_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+	return BMH_OK;
+}
+
+// ------------------------------------------------------------------ extend
+
+int bmh_extend_batch_device(bmh_ctx_t *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
+                            bmh_ext_result_t *d_res, const uint32_t *d_order)
+{
+	if (!ctx || n < 0 || (n > 0 && (!d_pool || !d_tasks || !d_res))) return BMH_E_ARG;
+	if (!ctx->have_params) return BMH_E_ARG;
+	if (n > 0xffffffffLL) return BMH_E_ARG;
+	BMH_HIP(ctx, hipSetDevice(ctx->device));
+	return launch_extend(ctx, d_pool, d_tasks, n, d_res, d_order, ctx->qcap);
+}
+
+// longest-first launch order (LPT): rows dominate the cost, ksw.c:411
+static void lpt_order(const bmh_ext_task_t *t, int64_t n, std::vector<uint32_t> &ord)
+{
+	ord.resize((size_t)n);
+	std::iota(ord.begin(), ord.end(), 0u);
+	std::stable_sort(ord.begin(), ord.end(), [t](uint32_t a, uint32_t b) {
+		const uint32_t ka = (uint32_t)t[a].tlen * 2 + (t[a].qlen > 64), kb = (uint32_t)t[b].tlen * 2 + (t[b].qlen > 64);
+		return ka > kb;
+	});
+}
+
+static int validate_ext(bmh_ctx *ctx, const bmh_ext_task_t *t, int64_t n, size_t pool_bytes, int *qmax)
+{
+	int qm = 1;
+	for (int64_t k = 0; k < n; ++k) {
+		const bmh_ext_task_t &x = t[k];
+		const bool qr = x.flags & BMH_F_QREV, tr = x.flags & BMH_F_TREV;
+		const uint64_t qlo = qr ? x.q_off - (x.qlen ? x.qlen - 1 : 0) : x.q_off, thi_len = x.tlen;
+		const uint64_t tlo = tr ? x.t_off - (x.tlen ? x.tlen - 1 : 0) : x.t_off;
+		if ((qr && x.qlen && x.q_off + 1 < x.qlen) || (tr && x.tlen && x.t_off + 1 < x.tlen) || qlo + x.qlen > pool_bytes ||
+		    tlo + thi_len > pool_bytes) {
+			ctx->last_error = "task " + std::to_string(k) + " reads outside the sequence pool";
+			return BMH_E_ARG;
+		}
+		const int h0 = x.h0 < 0 ? 0 : x.h0;
+		if ((int64_t)h0 + (int64_t)x.qlen * ctx->dev.max_mat > kScoreLimit) {
+			ctx->last_error = "task " + std::to_string(k) + ": h0 + qlen*max(mat) exceeds the 16-bit score range";
+			return BMH_E_RANGE;
+		}
+		qm = std::max(qm, (int)x.qlen);
+	}
+	*qmax = qm;
+	return BMH_OK;
+}
+
+int bmh_extend_batch(bmh_ctx_t *ctx, const uint8_t *pool, size_t pool_bytes, const bmh_ext_task_t *tasks, int64_t n,
+                     bmh_ext_result_t *results)
+{
+	if (!ctx || n < 0 || (n > 0 && (!tasks || !results))) return BMH_E_ARG;
+	if (!ctx->have_params) return BMH_E_ARG;
+	if (n == 0) return BMH_OK;
+	if (n > 0xffffffffLL) return BMH_E_ARG;
+	const bool resident = pool == nullptr; // use the pool left on the device by bmh_upload_pool()
+	if (resident) {
+		if (!ctx->pool_resident) return BMH_E_ARG;
+		pool_bytes = ctx->pool_bytes;
+	}
+	int qmax = 1, rc;
+	if ((rc = validate_ext(ctx, tasks, n, pool_bytes, &qmax))) return rc;
+	BMH_HIP(ctx, hipSetDevice(ctx->device));
+	std::vector<uint32_t> ord;
+	lpt_order(tasks, n, ord);
+	if (!resident) {
+		ctx->pool_resident = false;
+		if ((rc = ensure(ctx, ctx->d_pool, pool_bytes + 16))) return rc;
+	}
+	if ((rc = ensure(ctx, ctx->d_tasks, (size_t)n * sizeof(bmh_ext_task_t)))) return rc;
+	if ((rc = ensure(ctx, ctx->d_res, (size_t)n * sizeof(bmh_ext_result_t)))) return rc;
+	if ((rc = ensure(ctx, ctx->d_order, (size_t)n * 4))) return rc;
+	if (!resident) BMH_HIP(ctx, hipMemcpyAsync(ctx->d_pool.p, pool, pool_bytes, hipMemcpyHostToDevice, ctx->stream));
+	BMH_HIP(ctx, hipMemcpyAsync(ctx->d_tasks.p, tasks, (size_t)n * sizeof(bmh_ext_task_t), hipMemcpyHostToDevice, ctx->stream));
+	BMH_HIP(ctx, hipMemcpyAsync(ctx->d_order.p, ord.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+	if ((rc = launch_extend(ctx, (const uint8_t *)ctx->d_pool.p, (const bmh_ext_task_t *)ctx->d_tasks.p, n,
+	                        (bmh_ext_result_t *)ctx->d_res.p, (const uint32_t *)ctx->d_order.p, qmax)))
+		return rc;
+	BMH_HIP(ctx, hipMemcpyAsync(results, ctx->d_res.p, (size_t)n * sizeof(bmh_ext_result_t), hipMemcpyDeviceToHost, ctx->stream));
+	return fetch_err(ctx); // synchronises
+}
+
+int bmh_upload_pool(bmh_ctx_t *ctx, const uint8_t *pool, size_t bytes)
+{
+	if (!ctx || !pool) return BMH_E_ARG;
+	int rc;
+	BMH_HIP(ctx, hipSetDevice(ctx->device));
+	ctx->pool_resident = false;
+	if ((rc = ensure(ctx, ctx->d_pool, bytes + 16))) return rc;
+	BMH_HIP(ctx, hipMemcpyAsync(ctx->d_pool.p, pool, bytes, hipMemcpyHostToDevice, ctx->stream));
+	BMH_HIP(ctx, hipStreamSynchronize(ctx->stream)); // `pool` may be freed by the caller on return
+	ctx->pool_resident = true, ctx->pool_bytes = bytes;
+	return BMH_OK;
+}
+
+// internal hooks for host/chain2aln_batch.c (C cannot see inside bmh_ctx)
+const bmh_params_t *bmh_ctx_params_(const bmh_ctx_t *ctx) { return ctx && ctx->have_params ? &ctx->params : nullptr; }
+void bmh_ctx_set_driver_stats_(bmh_ctx_t *ctx, const bmh_driver_stats_t *st)
+{
+	if (ctx && st) ctx->dstats = *st;
+}
+
+int bmh_extend_batch_sharded(bmh_ctx_t *const *ctxs, int n_ctx, const uint8_t *pool, size_t pool_bytes,
+                             const bmh_ext_task_t *tasks, int64_t n, bmh_ext_result_t *results)
+{
+	if (!ctxs || n_ctx < 1 || n < 0) return BMH_E_ARG;
+	for (int g = 0; g < n_ctx; ++g)
+		if (!ctxs[g] || !ctxs[g]->have_params) return BMH_E_ARG;
+	if (n == 0) return BMH_OK;
+	// contiguous static split; every shard gets the whole pool (offsets stay valid), its own task slice
+	std::vector<std::vector<uint32_t>> ords((size_t)n_ctx);
+	std::vector<int64_t> lo((size_t)n_ctx + 1);
+	for (int g = 0; g <= n_ctx; ++g) lo[(size_t)g] = n * g / n_ctx;
+	int rc;
+	for (int g = 0; g < n_ctx; ++g) { // enqueue everything on every device before waiting on any
+		bmh_ctx *c = ctxs[g];
+		const int64_t m = lo[(size_t)g + 1] - lo[(size_t)g];
+		if (m == 0) continue;
+		const bmh_ext_task_t *t = tasks + lo[(size_t)g];
+		int qmax = 1;
+		if ((rc = validate_ext(c, t, m, pool_bytes, &qmax))) return rc;
+		BMH_HIP(c, hipSetDevice(c->device));
+		lpt_order(t, m, ords[(size_t)g]);
+		if ((rc = ensure(c, c->d_pool, pool_bytes + 16))) return rc;
+		if ((rc = ensure(c, c->d_tasks, (size_t)m * sizeof(bmh_ext_task_t)))) return rc;
+		if ((rc = ensure(c, c->d_res, (size_t)m * sizeof(bmh_ext_result_t)))) return rc;
+		if ((rc = ensure(c, c->d_order, (size_t)m * 4))) return rc;
+		BMH_HIP(c, hipMemcpyAsync(c->d_pool.p, pool, pool_bytes, hipMemcpyHostToDevice, c->stream));
+		BMH_HIP(c, hipMemcpyAsync(c->d_tasks.p, t, (size_t)m * sizeof(bmh_ext_task_t), hipMemcpyHostToDevice, c->stream));
+		BMH_HIP(c, hipMemcpyAsync(c->d_order.p, ords[(size_t)g].data(), (size_t)m * 4, hipMemcpyHostToDevice, c->stream));
+		if ((rc = launch_extend(c, (const uint8_t *)c->d_pool.p, (const bmh_ext_task_t *)c->d_tasks.p, m,
+		                        (bmh_ext_result_t *)c->d_res.p, (const uint32_t *)c->d_order.p, qmax)))
+			return rc;
+		BMH_HIP(c, hipMemcpyAsync(results + lo[(size_t)g], c->d_res.p, (size_t)m * sizeof(bmh_ext_result_t),
+		                          hipMemcpyDeviceToHost, c->stream));
+	}
+	int first = BMH_OK;
+	for (int g = 0; g < n_ctx; ++g) {
+		if (lo[(size_t)g + 1] == lo[(size_t)g]) continue;
+		BMH_HIP(ctxs[g], hipSetDevice(ctxs[g]->device));
+		rc = fetch_err(ctxs[g]);
+		if (rc && !first) first = rc;
+	}
+	return first;
+}
+
+// ------------------------------------------------------------------ global
+
+int bmh_global_batch_device(bmh_ctx_t *ctx, const uint8_t *d_pool, const bmh_glb_task_t *d_tasks, int64_t n,
+                            bmh_glb_result_t *d_res, uint32_t *d_cigar, const uint32_t *d_order)
+{
+	if (!ctx || n < 0 || (n > 0 && (!d_pool || !d_tasks || !d_res))) return BMH_E_ARG;
+	if (!ctx->have_params) return BMH_E_ARG;
+	if (n > 0xffffffffLL) return BMH_E_ARG;
+	BMH_HIP(ctx, hipSetDevice(ctx->device));
+	// no host view of the tasks: size for the context's capacity hint (square band-limited matrix)
+	return launch_global(ctx, d_pool, d_tasks, n, d_res, d_cigar, d_order, ctx->qcap, ctx->qcap + 2 * ctx->params.w + 64,
+	                     std::max(ctx->params.w * 4, 100));
+}
+
+int bmh_global_batch(bmh_ctx_t *ctx, const uint8_t *pool, size_t pool_bytes, const bmh_glb_task_t *tasks, int64_t n,
+                     bmh_glb_result_t *results, uint32_t *cigar_pool, size_t cigar_words)
+{
+	if (!ctx || n < 0 || (n > 0 && (!pool || !tasks || !results))) return BMH_E_ARG;
+	if (!ctx->have_params) return BMH_E_ARG;
+	if (n == 0) return BMH_OK;
+	if (n > 0xffffffffLL) return BMH_E_ARG;
+	int qmax = 1, tmax = 1, wmax = 0, rc;
+	for (int64_t k = 0; k < n; ++k) {
+		const bmh_glb_task_t &x = tasks[k];
+		if (x.q_off + x.qlen > pool_bytes || x.t_off + x.tlen > pool_bytes || x.w < 0 ||
+		    (x.cigar_cap && (!cigar_pool || (size_t)x.cigar_off + x.cigar_cap > cigar_words))) {
+			ctx->last_error = "global task " + std::to_string(k) + " has out-of-range offsets";
+			return BMH_E_ARG;
+		}
+		qmax = std::max(qmax, (int)x.qlen), tmax = std::max(tmax, (int)x.tlen);
+		wmax = std::max(wmax, std::min(x.w, (int)x.qlen)); // only min(qlen,2w+1) columns are ever stored
+	}
+	BMH_HIP(ctx, hipSetDevice(ctx->device));
+	std::vector<uint32_t> ord((size_t)n);
+	std::iota(ord.begin(), ord.end(), 0u);
+	std::stable_sort(ord.begin(), ord.end(), [tasks](uint32_t a, uint32_t b) { return tasks[a].tlen > tasks[b].tlen; });
+	if ((rc = ensure(ctx, ctx->d_pool, pool_bytes + 16))) return rc;
+	if ((rc = ensure(ctx, ctx->d_tasks, (size_t)n * sizeof(bmh_glb_task_t)))) return rc;
+	if ((rc = ensure(ctx, ctx->d_res, (size_t)n * sizeof(bmh_glb_result_t)))) return rc;
+	if ((rc = ensure(ctx, ctx->d_order, (size_t)n * 4))) return rc;
+	if ((rc = ensure(ctx, ctx->d_cigar, (cigar_words + 4) * 4))) return rc;
+	BMH_HIP(ctx, hipMemcpyAsync(ctx->d_pool.p, pool, pool_bytes, hipMemcpyHostToDevice, ctx->stream));
+	BMH_HIP(ctx, hipMemcpyAsync(ctx->d_tasks.p, tasks, (size_t)n * sizeof(bmh_glb_task_t), hipMemcpyHostToDevice, ctx->stream));
+	BMH_HIP(ctx, hipMemcpyAsync(ctx->d_order.p, ord.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+	if ((rc = launch_global(ctx, (const uint8_t *)ctx->d_pool.p, (const bmh_glb_task_t *)ctx->d_tasks.p, n,
+	                        (bmh_glb_result_t *)ctx->d_res.p, (uint32_t *)ctx->d_cigar.p, (const uint32_t *)ctx->d_order.p, qmax,
+	                        tmax, wmax)))
+		return rc;
+	BMH_HIP(ctx, hipMemcpyAsync(results, ctx->d_res.p, (size_t)n * sizeof(bmh_glb_result_t), hipMemcpyDeviceToHost, ctx->stream));
+	if (cigar_words)
+		BMH_HIP(ctx, hipMemcpyAsync(cigar_pool, ctx->d_cigar.p, cigar_words * 4, hipMemcpyDeviceToHost, ctx->stream));
+	return fetch_err(ctx);
+}
+
+int bmh_driver_stats(const bmh_ctx_t *ctx, bmh_driver_stats_t *st)
+{
+	if (!ctx || !st) return BMH_E_ARG;
+	*st = ctx->dstats;
+	return BMH_OK;
+}
+
+} // extern "C"

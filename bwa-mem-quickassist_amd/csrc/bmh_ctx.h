@@ -1,0 +1,54 @@
+// bmh_ctx.h -- host-side context shared by the C-ABI translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/bwamem_hip.h"
+#include "bmh_device.h"
+
+struct DevBuf { // grow-only device allocation
+	void *p = nullptr;
+	size_t cap = 0;
+};
+
+struct bmh_ctx {
+	int device = 0;
+	hipStream_t own_stream = nullptr, stream = nullptr;
+	bool have_params = false;
+	bmh_params_t params{};
+	bmh::DevParams dev{};
+	int qcap = 512; // query-length capacity used to size the LDS kernel's window state for *_device calls
+	// device workspaces of the host-buffer entry points
+	DevBuf d_pool, d_tasks, d_res, d_order, d_cigar, d_scratch;
+	bool pool_resident = false; // d_pool holds a pool uploaded by bmh_upload_pool()
+	size_t pool_bytes = 0;
+	int *d_err = nullptr; // device error flag (BMH_E_* or 0)
+	int *h_err = nullptr; // pinned mirror
+	// kernel timing
+	bool timing = false;
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	bool ev_valid = false;
+	std::string last_error;
+	bmh_driver_stats_t dstats{};
+};
+
+namespace bmh {
+
+int set_hip_error(bmh_ctx *ctx, hipError_t e, const char *what);
+int ensure(bmh_ctx *ctx, DevBuf &b, size_t bytes);
+
+#define BMH_HIP(ctx, call)                                                   \
+	do {                                                                     \
+		hipError_t e_ = (call);                                              \
+		if (e_ != hipSuccess) return bmh::set_hip_error((ctx), e_, #call);   \
+	} while (0)
+
+// kernel launchers (defined next to the kernels)
+int launch_extend(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
+                  bmh_ext_result_t *d_res, const uint32_t *d_order, int qmax);
+int launch_global(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_glb_task_t *d_tasks, int64_t n,
+                  bmh_glb_result_t *d_res, uint32_t *d_cigar, const uint32_t *d_order, int qmax, int tmax,
+                  int wmax);
+
+} // namespace bmh

@@ -1,0 +1,78 @@
+// bmh_device.h -- device-side helpers shared by the gfx950 kernels.
+// wave64 only (CDNA4): every cross-lane primitive here assumes 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/bwamem_hip.h"
+
+namespace bmh {
+
+// Scoring constants, passed by value in the kernarg segment (uniform -> SGPRs).
+struct DevParams {
+	int o_del, e_del, o_ins, e_ins, zdrop;
+	int max_mat;      // max entry of mat[] (ksw.c:398-400), precomputed on the host
+	uint32_t matw[7]; // mat[25] as bytes, little endian, padded to 28
+};
+
+constexpr int kScoreLimit = 32000; // h0 + qlen*max_mat must stay below this (16-bit lanes)
+constexpr int kNegInf16 = -16384;  // scan identity for 16-bit-ranged values held in int32
+
+// ---- DPP controls (GFX9 encoding) ----
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
+constexpr int DPP_WAVE_SHR1 = 0x138, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ int dpp(int old, int src)
+{
+	return __builtin_amdgcn_update_dpp(old, src, CTRL, ROW_MASK, 0xf, false);
+}
+
+// inclusive prefix max over the 64 lanes (6 VALU+DPP steps, no LDS).
+// The DPP `old` operand is INT32_MIN, the identity of signed max, which lets
+// hipcc's DPP combiner fold each step into a single v_max_i32_dpp.
+__device__ __forceinline__ int wave_scan_max(int v)
+{
+	constexpr int I = INT32_MIN;
+	v = max(dpp<DPP_ROW_SHR1>(I, v), v);
+	v = max(dpp<DPP_ROW_SHR2>(I, v), v);
+	v = max(dpp<DPP_ROW_SHR4>(I, v), v);
+	v = max(dpp<DPP_ROW_SHR8>(I, v), v);
+	v = max(dpp<DPP_ROW_BCAST15, 0xa>(I, v), v);
+	v = max(dpp<DPP_ROW_BCAST31, 0xc>(I, v), v);
+	return v;
+}
+
+// max over the wave, returned as a wave-uniform value
+__device__ __forceinline__ int wave_reduce_max(int v)
+{
+	return __builtin_amdgcn_readlane(wave_scan_max(v), 63);
+}
+
+// value of lane-1 (lane 0 receives `lane0`)
+__device__ __forceinline__ int wave_shr1(int v, int lane0)
+{
+	return dpp<DPP_WAVE_SHR1>(lane0, v);
+}
+
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ int mat_at(const DevParams &P, int idx)
+{
+	return (int)(int8_t)(P.matw[idx >> 2] >> ((idx & 3) * 8));
+}
+
+// sequence base k of a task: forward pool[off+k], reversed pool[off-k]
+__device__ __forceinline__ int seq_base(const uint8_t *pool, uint64_t off, int k, bool rev)
+{
+	return rev ? pool[off - (uint64_t)k] : pool[off + (uint64_t)k];
+}
+
+// ksw.c:401-405 without floating point: trunc((x)/e + 1) floored at 1 equals x/e+1 for x>=0, else 1 (e>=1)
+__device__ __forceinline__ int band_cap(int qlen, int mx, int end_bonus, int o, int e)
+{
+	int x = qlen * mx + end_bonus - o;
+	return x >= 0 ? x / e + 1 : 1;
+}
+
+} // namespace bmh

@@ -1,0 +1,87 @@
+/*
+ * dropin.c -- per-call drop-ins with the EXACT ksw.h signatures (reference
+ * bwa-0.7.8/ksw.h:84 and :108), each call offloaded to the GPU as a batch of one.
+ * Built into libbwamem_hip_dropin.so.  They exist for parity work -- link or
+ * LD_PRELOAD them in front of the reference's ksw.o and the whole-SAM DUT/REF diff
+ * of SURVEY.md §4 exercises the kernels through the untouched host pipeline.  They
+ * are slow by construction (one launch per call); production goes through the
+ * batched seam in interpose.c / bmh_chain2aln_batch.
+ *
+ * Failure convention = the reference's: there is no error return on
+ * this path, so any library error aborts loudly; nothing falls back to the CPU.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/bwamem_hip.h"
+#include "tls_ctx.h"
+
+int ksw_extend2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int m, const int8_t *mat, int o_del,
+                int e_del, int o_ins, int e_ins, int w, int end_bonus, int zdrop, int h0, int *qle, int *tle, int *gtle,
+                int *gscore, int *max_off)
+{
+	bmh_params_t p;
+	bmh_ext_task_t t;
+	bmh_ext_result_t r;
+	uint8_t *pool;
+	bmh_ctx_t *ctx;
+	int rc;
+	if (m != 5) bmh_tls_die("ksw_extend2 drop-in supports m == 5 only", BMH_E_RANGE);
+	memset(&p, 0, sizeof(p));
+	p.o_del = o_del, p.e_del = e_del, p.o_ins = o_ins, p.e_ins = e_ins, p.zdrop = zdrop;
+	p.a = 1, p.w = w, p.pen_clip5 = p.pen_clip3 = end_bonus;
+	memcpy(p.mat, mat, 25);
+	ctx = bmh_tls_ctx(&p);
+	pool = (uint8_t *)malloc((size_t)qlen + (size_t)tlen + 16);
+	memcpy(pool, query, (size_t)qlen);
+	memcpy(pool + qlen, target, (size_t)tlen);
+	memset(&t, 0, sizeof(t));
+	if (qlen > 65535 || tlen > 65535 || w > 32767 || w < -32768) bmh_tls_die("ksw_extend2 drop-in: lengths out of range", BMH_E_RANGE);
+	t.q_off = 0, t.t_off = (uint64_t)qlen, t.qlen = (uint16_t)qlen, t.tlen = (uint16_t)tlen;
+	t.h0 = h0, t.w = (int16_t)w, t.end_bonus = (int16_t)end_bonus;
+	if ((rc = bmh_extend_batch(ctx, pool, (size_t)qlen + (size_t)tlen + 16, &t, 1, &r))) bmh_tls_die(bmh_last_error(ctx), rc);
+	free(pool);
+	if (qle) *qle = r.qle; /* NULL out-pointers allowed, ksw.c:470-474 */
+	if (tle) *tle = r.tle;
+	if (gtle) *gtle = r.gtle;
+	if (gscore) *gscore = r.gscore;
+	if (max_off) *max_off = r.max_off;
+	return r.score;
+}
+
+int ksw_global2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int m, const int8_t *mat, int o_del,
+                int e_del, int o_ins, int e_ins, int w, int *n_cigar_, uint32_t **cigar_)
+{
+	bmh_params_t p;
+	bmh_glb_task_t t;
+	bmh_glb_result_t r;
+	uint8_t *pool;
+	uint32_t *cig = 0;
+	bmh_ctx_t *ctx;
+	int rc, want = n_cigar_ && cigar_; /* ksw.c:566 */
+	if (m != 5) bmh_tls_die("ksw_global2 drop-in supports m == 5 only", BMH_E_RANGE);
+	if (n_cigar_) *n_cigar_ = 0; /* ksw.c:507 */
+	memset(&p, 0, sizeof(p));
+	p.o_del = o_del, p.e_del = e_del, p.o_ins = o_ins, p.e_ins = e_ins, p.zdrop = 0, p.a = 1, p.w = 100;
+	memcpy(p.mat, mat, 25);
+	ctx = bmh_tls_ctx(&p);
+	if (qlen > 65535 || tlen > 65535) bmh_tls_die("ksw_global2 drop-in: lengths out of range", BMH_E_RANGE);
+	pool = (uint8_t *)malloc((size_t)qlen + (size_t)tlen + 16);
+	memcpy(pool, query, (size_t)qlen);
+	memcpy(pool + qlen, target, (size_t)tlen);
+	memset(&t, 0, sizeof(t));
+	t.q_off = 0, t.t_off = (uint64_t)qlen, t.qlen = (uint16_t)qlen, t.tlen = (uint16_t)tlen, t.w = w;
+	if (want) {
+		t.cigar_cap = (uint32_t)(qlen + tlen + 2);
+		cig = (uint32_t *)malloc((size_t)t.cigar_cap * 4); /* caller frees, ksw.h:79 */
+	}
+	if ((rc = bmh_global_batch(ctx, pool, (size_t)qlen + (size_t)tlen + 16, &t, 1, &r, cig, want ? t.cigar_cap : 0)))
+		bmh_tls_die(bmh_last_error(ctx), rc);
+	free(pool);
+	if (want) {
+		if (r.n_cigar == 0) free(cig), cig = 0; /* the reference leaves a NULL pointer when nothing was pushed */
+		*n_cigar_ = r.n_cigar, *cigar_ = cig;
+	}
+	return r.score;
+}

@@ -1,0 +1,98 @@
+/*
+ * interpose.c -- the reference-side binding, as an LD_PRELOAD-able object.
+ *
+ * It provides mem_align1_core_batched() with the fork's exact signature
+ * (reference bwa-0.7.8/bwamem.c:1086) so that, preloaded in front of a build of the
+ * reference (oracle/_ref/bwa + libbwa_ref.so), phase 1 of mem_process_seqs
+ * (bwamem.c:1313 -> worker1_batched :1264) runs seeding/chaining on the CPU exactly
+ * as before and hands every batch's chains to bmh_chain2aln_batch() -- the hook the
+ * fork left commented out at bwamem.c:1110.  Run `bwa mem -b <batch>` to choose the
+ * batch size.  INTEGRATION.md shows the same code as a patch to bwamem.c.
+ *
+ * Everything declared `extern` below is the reference's own symbol, resolved at load
+ * time from libbwa_ref.so; nothing of the reference is compiled into this library.
+ * The struct mirrors are layout-compatible re-declarations (file:line cited).
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/bwamem_hip.h"
+#include "tls_ctx.h"
+
+typedef struct { /* mem_opt_t of the fork, bwamem.h:21-48 */
+	int a, b, o_del, e_del, o_ins, e_ins, pen_unpaired, pen_clip5, pen_clip3, w, zdrop;
+	int T, flag, min_seed_len;
+	float split_factor;
+	int split_width, max_occ, max_chain_gap, n_threads, batch_size, chunk_size;
+	float mask_level, chain_drop_ratio, mask_level_redun, mapQ_coef_len;
+	int mapQ_coef_fac, max_ins, max_matesw;
+	int8_t mat[25];
+} ref_mem_opt_t;
+#define REF_MEM_F_NO_EXACT 0x40 /* bwamem.h:19 */
+
+typedef struct { int64_t l_pac; /* first field of bntseq_t, bntseq.h:53 */ } ref_bntseq_head_t;
+typedef struct { int l_seq; char *name, *comment, *seq, *qual, *sam; } ref_bseq1_t; /* bwa.h:18-22 */
+
+/* reference functions this shim keeps calling on the CPU (bwamem.c:283,319,395,438,495; bntseq.c) */
+extern bmh_chain_v mem_chain(const void *opt, const void *bwt, int64_t l_pac, int len, const uint8_t *seq);
+extern int mem_chain_flt(const void *opt, int n_chn, bmh_chain_t *chains);
+extern int mem_chain2aln_short(const void *opt, int64_t l_pac, const uint8_t *pac, int l_query, const uint8_t *query,
+                               const bmh_chain_t *c, bmh_alnreg_v *av);
+extern int mem_sort_and_dedup(int n, bmh_alnreg_t *a, float mask_level_redun);
+extern int mem_test_and_remove_exact(const void *opt, int n, bmh_alnreg_t *a, int qlen);
+extern unsigned char nst_nt4_table[256];
+
+typedef struct {
+	const ref_mem_opt_t *opt;
+	int64_t l_pac;
+	const uint8_t *pac;
+	const bmh_read_t *reads;
+	const bmh_chain_v *chains;
+} pre_ud_t;
+
+static int pre_short(void *user, int r, int ci, bmh_alnreg_v *av) /* bwamem.c:1104 */
+{
+	const pre_ud_t *u = (const pre_ud_t *)user;
+	return mem_chain2aln_short(u->opt, u->l_pac, u->pac, u->reads[r].l_seq, u->reads[r].seq, &u->chains[r].a[ci], av);
+}
+
+bmh_alnreg_v *mem_align1_core_batched(const ref_mem_opt_t *opt, const void *bwt, const ref_bntseq_head_t *bns,
+                                      const uint8_t *pac, ref_bseq1_t *seqs, int start, int batch_size)
+{
+	bmh_chain_v *chn = (bmh_chain_v *)malloc(sizeof(bmh_chain_v) * (size_t)batch_size);
+	bmh_alnreg_v *regs = (bmh_alnreg_v *)calloc((size_t)batch_size, sizeof(bmh_alnreg_v));
+	bmh_read_t *reads = (bmh_read_t *)malloc(sizeof(bmh_read_t) * (size_t)batch_size);
+	bmh_params_t p;
+	bmh_ctx_t *ctx;
+	pre_ud_t ud;
+	int b, i, rc;
+
+	for (b = 0; b < batch_size; ++b) { /* CPU stages before the path, unchanged: bwamem.c:1093-1097 */
+		ref_bseq1_t *s = &seqs[start + b];
+		for (i = 0; i < s->l_seq; ++i) s->seq[i] = s->seq[i] < 4 ? s->seq[i] : (char)nst_nt4_table[(int)s->seq[i]];
+		chn[b] = mem_chain(opt, bwt, bns->l_pac, s->l_seq, (uint8_t *)s->seq);
+		chn[b].n = (size_t)mem_chain_flt(opt, (int)chn[b].n, chn[b].a);
+		reads[b].l_seq = s->l_seq, reads[b].seq = (const uint8_t *)s->seq;
+	}
+
+	memset(&p, 0, sizeof(p)); /* the hot-path fields of mem_opt_t */
+	p.o_del = opt->o_del, p.e_del = opt->e_del, p.o_ins = opt->o_ins, p.e_ins = opt->e_ins, p.zdrop = opt->zdrop;
+	p.a = opt->a, p.w = opt->w, p.pen_clip5 = opt->pen_clip5, p.pen_clip3 = opt->pen_clip3;
+	memcpy(p.mat, opt->mat, 25);
+	ctx = bmh_tls_ctx(&p);
+	ud.opt = opt, ud.l_pac = bns->l_pac, ud.pac = pac, ud.reads = reads, ud.chains = chn;
+	if ((rc = bmh_chain2aln_batch(ctx, bns->l_pac, pac, batch_size, reads, chn, pre_short, &ud, regs))) /* bwamem.c:1110 */
+		bmh_tls_die(bmh_last_error(ctx), rc);
+
+	for (b = 0; b < batch_size; ++b) { /* CPU stages after the path, unchanged: bwamem.c:1106,1112-1117 */
+		for (i = 0; i < (int)chn[b].n; ++i) free(chn[b].a[i].seeds);
+		free(chn[b].a);
+		regs[b].n = (size_t)mem_sort_and_dedup((int)regs[b].n, regs[b].a, opt->mask_level_redun);
+		if (opt->flag & REF_MEM_F_NO_EXACT)
+			regs[b].n = (size_t)mem_test_and_remove_exact(opt, (int)regs[b].n, regs[b].a, seqs[start + b].l_seq);
+	}
+	free(chn);
+	free(reads);
+	return regs; /* caller copies and frees, bwamem.c:1272-1278 */
+}

@@ -1,0 +1,159 @@
+/*
+ * taskgen.c -- synthetic workload generator for bench.py and the full-size tests
+ * (libbmh_taskgen.so).  Not part of the product path and not part of the oracle.
+ *
+ * There is no genome or FASTQ data on the build or GPU machines, and an hg38-scale
+ * FM-index cannot be built there, so the extension kernel is driven
+ * with the tasks mem_chain2aln() (reference bwa-0.7.8/bwamem.c:730-878) WOULD build
+ * for simulated reads:
+ *
+ *   reference window = uniform random bases; read = window slice with substitutions,
+ *   insertions, deletions (optionally N's and a chimeric random tail);
+ *   seeds   = error-free runs of >= min_seed_len bases along the true diagonal (what
+ *             SMEM seeding yields on a repeat-free genome, bwamem.c:118-157);
+ *   window  = [rmax0,rmax1) over all seeds (bwamem.c:740-751);
+ *   tasks   = left + right extension of the longest seed (the other seeds lie inside
+ *             the resulting region and are skipped, bwamem.c:769-799):
+ *             left : reversed flanks, h0 = len*a, end_bonus = pen_clip5   (bwamem.c:810-829)
+ *             right: forward flanks,  h0 ~ left score, end_bonus = pen_clip3 (bwamem.c:841-857)
+ *
+ * The right task's h0 is the exact score of the true left alignment floored at the
+ * seed score (the real value needs the left DP first); parity is unaffected because GPU
+ * and oracle consume the same task records.
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/bwamem_hip.h"
+
+typedef struct {
+	uint64_t seed;
+	int32_t len_min, len_max;   /* read length range                         */
+	int32_t min_seed_len;       /* 19, bwamem.c:58                            */
+	int32_t max_indel;          /* indel lengths uniform in 1..max_indel     */
+	double p_sub, p_ins, p_del; /* per-base event probabilities              */
+	double p_n;                 /* per-base probability of an N in the read  */
+	double p_chimera;           /* probability the read tail is unrelated    */
+} bmh_taskgen_cfg_t;
+
+static inline uint64_t splitmix(uint64_t *s)
+{
+	uint64_t z = (*s += 0x9e3779b97f4a7c15ULL);
+	z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+	z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+	return z ^ (z >> 31);
+}
+static inline double urand(uint64_t *s) { return (double)(splitmix(s) >> 11) * (1.0 / 9007199254740992.0); }
+static inline int irand(uint64_t *s, int lo, int hi) { return lo + (int)(splitmix(s) % (uint64_t)(hi - lo + 1)); }
+
+static int cal_max_gap(const bmh_params_t *p, int qlen) /* bwamem.c:544-551 */
+{
+	int l_del = (int)((double)(qlen * p->a - p->o_del) / p->e_del + 1.);
+	int l_ins = (int)((double)(qlen * p->a - p->o_ins) / p->e_ins + 1.);
+	int l = l_del > l_ins ? l_del : l_ins;
+	l = l > 1 ? l : 1;
+	return l < p->w << 1 ? l : p->w << 1;
+}
+
+/* Upper bounds so callers can size buffers: bytes of pool and tasks per read. */
+size_t bmh_taskgen_pool_bound(const bmh_taskgen_cfg_t *c, const bmh_params_t *p)
+{
+	return (size_t)c->len_max * 4 + (size_t)p->w * 4 + 64;
+}
+
+/* Generates tasks for reads [0,n_reads).  Returns the number of tasks, or -1 if a
+ * capacity is too small.  task_read (nullable) receives the read index of each task. */
+int64_t bmh_taskgen_ext(const bmh_taskgen_cfg_t *cfg, const bmh_params_t *p, int64_t n_reads, uint8_t *pool,
+                        size_t pool_cap, size_t *pool_used, bmh_ext_task_t *tasks, int64_t task_cap,
+                        uint32_t *task_read)
+{
+	const int Lmax = cfg->len_max;
+	const int G = (p->w << 1) + Lmax + 8; /* flank of reference kept on each side */
+	const int R = Lmax * 2 + 2 * G + 64;
+	uint8_t *ref = (uint8_t *)malloc((size_t)R), *rd = (uint8_t *)malloc((size_t)Lmax + 64);
+	int *rpos = (int *)malloc(sizeof(int) * ((size_t)Lmax + 64)); /* ref index of a copied base, -1 = not a clean copy */
+	int64_t nt = 0, r;
+	size_t used = 0;
+	uint64_t s = cfg->seed;
+
+	for (r = 0; r < n_reads; ++r) {
+		const int L = irand(&s, cfg->len_min, cfg->len_max);
+		int i, x, n = 0, best_q = -1, best_len = 0, best_r = -1, run_q = 0, run_len = 0;
+		int chim_at = (cfg->p_chimera > 0 && urand(&s) < cfg->p_chimera && L > 40) ? irand(&s, 20, L - 1) : L + 1;
+		int64_t rmax0 = 1 << 30, rmax1 = 0;
+		for (i = 0; i < R; ++i) ref[i] = (uint8_t)(splitmix(&s) & 3);
+		/* read = ref[G ...] with errors */
+		for (x = G; n < L && x < R - 1;) {
+			const double u = urand(&s);
+			if (n >= chim_at) { rd[n] = (uint8_t)(splitmix(&s) & 3), rpos[n] = -1, ++n, ++x; continue; }
+			if (u < cfg->p_sub) rd[n] = (uint8_t)((ref[x] + 1 + splitmix(&s) % 3) & 3), rpos[n] = -1, ++n, ++x;
+			else if (u < cfg->p_sub + cfg->p_ins) {
+				int k = irand(&s, 1, cfg->max_indel);
+				for (; k > 0 && n < L; --k) rd[n] = (uint8_t)(splitmix(&s) & 3), rpos[n] = -1, ++n;
+			} else if (u < cfg->p_sub + cfg->p_ins + cfg->p_del) x += irand(&s, 1, cfg->max_indel);
+			else rd[n] = ref[x], rpos[n] = x, ++n, ++x;
+		}
+		if (n < L) continue;
+		if (cfg->p_n > 0)
+			for (i = 0; i < L; ++i)
+				if (urand(&s) < cfg->p_n) rd[i] = 4, rpos[i] = -1;
+		/* seeds = maximal clean diagonal runs >= min_seed_len; chain window over all of them */
+		for (i = 0; i <= L; ++i) {
+			const int cont = i < L && rpos[i] >= 0 && run_len > 0 && rpos[i] == rpos[i - 1] + 1;
+			if (cont) { ++run_len; continue; }
+			if (run_len >= cfg->min_seed_len) {
+				const int qb = run_q, rb = rpos[run_q], rest = L - qb - run_len;
+				const int64_t b = rb - (qb + cal_max_gap(p, qb)), e = rb + run_len + (rest + cal_max_gap(p, rest));
+				if (b < rmax0) rmax0 = b;
+				if (e > rmax1) rmax1 = e;
+				if (run_len > best_len) best_len = run_len, best_q = qb, best_r = rb;
+			}
+			if (i < L && rpos[i] >= 0) run_q = i, run_len = 1;
+			else run_len = 0;
+		}
+		if (best_len == 0) continue; /* unseeded read: no extension work */
+		if (rmax0 < 0) rmax0 = 0;
+		if (rmax1 > R) rmax1 = R;
+		if (used + (size_t)L + (size_t)(rmax1 - rmax0) + 16 > pool_cap || nt + 2 > task_cap) {
+			nt = -1;
+			break;
+		}
+		{
+			const uint64_t read_off = used, win_off = used + (uint64_t)L;
+			int lsc = best_len * p->a;
+			memcpy(pool + read_off, rd, (size_t)L);
+			memcpy(pool + win_off, ref + rmax0, (size_t)(rmax1 - rmax0));
+			used += (size_t)L + (size_t)(rmax1 - rmax0);
+			if (best_q > 0) { /* left extension */
+				bmh_ext_task_t *t = &tasks[nt];
+				const int tl = (int)(best_r - rmax0);
+				int sc = 0, bestsc = 0;
+				memset(t, 0, sizeof(*t));
+				t->q_off = read_off + (uint64_t)(best_q - 1), t->t_off = win_off + (uint64_t)(tl > 0 ? tl - 1 : 0);
+				t->qlen = (uint16_t)best_q, t->tlen = (uint16_t)tl, t->h0 = best_len * p->a;
+				t->w = (int16_t)p->w, t->end_bonus = (int16_t)p->pen_clip5, t->flags = BMH_F_QREV | BMH_F_TREV;
+				if (task_read) task_read[nt] = (uint32_t)r;
+				++nt;
+				for (i = best_q - 1; i >= 0; --i) { /* crude score of the true left alignment, for the right h0 */
+					sc += rpos[i] >= 0 ? p->a : -4;
+					if (sc > bestsc) bestsc = sc;
+				}
+				lsc += bestsc;
+			}
+			if (best_q + best_len < L) { /* right extension */
+				bmh_ext_task_t *t = &tasks[nt];
+				const int qe = best_q + best_len;
+				const int64_t re = best_r + best_len - rmax0;
+				memset(t, 0, sizeof(*t));
+				t->q_off = read_off + (uint64_t)qe, t->t_off = win_off + (uint64_t)re;
+				t->qlen = (uint16_t)(L - qe), t->tlen = (uint16_t)(rmax1 - rmax0 - re), t->h0 = lsc;
+				t->w = (int16_t)p->w, t->end_bonus = (int16_t)p->pen_clip3;
+				if (task_read) task_read[nt] = (uint32_t)r;
+				++nt;
+			}
+		}
+	}
+	free(ref), free(rd), free(rpos);
+	if (pool_used) *pool_used = used;
+	return nt;
+}

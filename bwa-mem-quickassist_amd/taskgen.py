@@ -1,0 +1,59 @@
+"""ctypes view of libbmh_taskgen.so (host/taskgen.c): synthetic extension workloads that
+follow the task distribution mem_chain2aln produces.  Bench/test support."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+TASKGEN_PATH = os.path.join(_HERE, "libbmh_taskgen.so")
+
+
+class Cfg(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("len_min", C.c_int32), ("len_max", C.c_int32),
+                ("min_seed_len", C.c_int32), ("max_indel", C.c_int32), ("p_sub", C.c_double),
+                ("p_ins", C.c_double), ("p_del", C.c_double), ("p_n", C.c_double), ("p_chimera", C.c_double)]
+
+
+# BASELINE.json configs -> error models
+WORKLOADS = {
+    # C2-C4: 150 bp reads, 2 % subst + 0.25 % ins + 0.25 % del
+    "150bp": dict(len_min=150, len_max=150, min_seed_len=19, max_indel=1, p_sub=0.02, p_ins=0.0025, p_del=0.0025,
+                  p_n=0.0, p_chimera=0.0),
+    # C5: mixed 100-300 bp, indels 1-12, 30 % chimeric tails, 4 % N ("long-band stress")
+    "mixed100-300": dict(len_min=100, len_max=300, min_seed_len=19, max_indel=12, p_sub=0.03, p_ins=0.005,
+                         p_del=0.005, p_n=0.04, p_chimera=0.3),
+}
+
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(TASKGEN_PATH)
+        L.bmh_taskgen_ext.restype = C.c_int64
+        L.bmh_taskgen_pool_bound.restype = C.c_size_t
+        _lib = L
+    return _lib
+
+
+def generate(params, n_reads, workload="150bp", seed=7, ext_task_dtype=None):
+    """Returns (pool uint8[], tasks EXT_TASK[], task_read uint32[])."""
+    from . import EXT_TASK, PARAMS
+    L = _load()
+    cfg = Cfg(seed=seed, **WORKLOADS[workload])
+    p = np.ascontiguousarray(np.asarray(params, dtype=PARAMS).reshape(()))
+    bound = L.bmh_taskgen_pool_bound(C.byref(cfg), p.ctypes.data_as(C.c_void_p))
+    pool = np.empty(int(bound) * int(n_reads) + 64, dtype=np.uint8)
+    tasks = np.empty(2 * int(n_reads) + 2, dtype=EXT_TASK)
+    tread = np.empty(2 * int(n_reads) + 2, dtype=np.uint32)
+    used = C.c_size_t(0)
+    nt = L.bmh_taskgen_ext(C.byref(cfg), p.ctypes.data_as(C.c_void_p), C.c_int64(n_reads),
+                           pool.ctypes.data_as(C.c_void_p), C.c_size_t(pool.nbytes), C.byref(used),
+                           tasks.ctypes.data_as(C.c_void_p), C.c_int64(len(tasks)), tread.ctypes.data_as(C.c_void_p))
+    if nt < 0:
+        raise RuntimeError("taskgen capacity too small")
+    pool = pool[: used.value + 16]
+    pool[used.value:] = 0
+    return pool, tasks[:nt].copy(), tread[:nt].copy()

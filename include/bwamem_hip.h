@@ -116,7 +116,10 @@ int bmh_ctx_destroy(bmh_ctx_t *ctx);
 int bmh_ctx_set_params(bmh_ctx_t *ctx, const bmh_params_t *p);
 /* Run on a caller-owned hipStream_t (passed as void*); NULL restores the context's own. */
 int bmh_ctx_set_stream(bmh_ctx_t *ctx, void *hip_stream);
-int bmh_ctx_sync(bmh_ctx_t *ctx);
+int bmh_ctx_sync(bmh_ctx_t *ctx); /* waits for the stream; returns a pending BMH_E_RANGE/CIGAR_CAP of a *_device call */
+/* Capacity hint for the *_device entry points, which cannot look at the tasks on the host:
+ * the longest query the launch must handle (default 512).  Longer tasks fail with BMH_E_RANGE. */
+int bmh_ctx_set_qcap(bmh_ctx_t *ctx, int max_qlen);
 
 /* ---- L2, host buffers: H2D copy, launch, D2H copy, synchronous on return. */
 int bmh_extend_batch(bmh_ctx_t *ctx, const uint8_t *seqpool, size_t pool_bytes,
@@ -124,6 +127,10 @@ int bmh_extend_batch(bmh_ctx_t *ctx, const uint8_t *seqpool, size_t pool_bytes,
 int bmh_global_batch(bmh_ctx_t *ctx, const uint8_t *seqpool, size_t pool_bytes,
                      const bmh_glb_task_t *tasks, int64_t n, bmh_glb_result_t *results,
                      uint32_t *cigar_pool, size_t cigar_pool_words);
+
+/* Leave a sequence pool resident on the device; afterwards bmh_extend_batch(ctx, NULL, 0, ...)
+ * runs tasks against it without re-uploading (the L3 driver uploads once per read batch). */
+int bmh_upload_pool(bmh_ctx_t *ctx, const uint8_t *seqpool, size_t pool_bytes);
 
 /* ---- L2, device-resident buffers: asynchronous on the context's stream.
  * `d_order` (nullable) is a device array of n task indices giving the launch
@@ -182,16 +189,20 @@ typedef struct bmh_read { /* the two bseq1_t fields the driver reads (bwa.h:18-2
 	const uint8_t *seq; /* base codes 0..4 (after bwamem.c:1093-1094) */
 } bmh_read_t;
 
+/* Optional per-chain pre-step, called right before chain `chain` of read `read` would be
+ * extended, in the reference's order.  It mirrors `ret = mem_chain2aln_short(...)`
+ * (bwamem.c:1104 / :1140): it may append to *av; a return value <= 0 means the chain is
+ * done and must not be extended, > 0 means "run mem_chain2aln on it" (bwamem.c:1105). */
+typedef int (*bmh_chain_pre_fn)(void *user, int read, int chain, bmh_alnreg_v *av);
+
 /* Replaces, for `n_reads` reads at once, the loop
- *     for each chain c of read r: mem_chain2aln(opt,l_pac,pac,l_seq,seq,c,&regs[r])
- * (bwamem.c:1101-1107 / :1136-1143).  Regions are APPENDED to regs[r] (kv_pushp
- * semantics, bwamem.c:804), so entries already there (e.g. from
- * mem_chain2aln_short) take part in the containment test of bwamem.c:769-802.
- * `skip` (nullable): skip[r][c] != 0 means chain c of read r was already
- * handled (mem_chain2aln_short returned 0) and must not be extended. */
+ *     for each chain c of read r: [pre-step;] mem_chain2aln(opt,l_pac,pac,l_seq,seq,c,&regs[r])
+ * (bwamem.c:1101-1107 / :1136-1143).  Regions are APPENDED to regs[r] (kv_pushp semantics,
+ * bwamem.c:804; regs[r].a must be NULL or malloc'd), so entries already there take part in
+ * the containment test of bwamem.c:769-802.  `pre` may be NULL (every chain is extended). */
 int bmh_chain2aln_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n_reads,
-                        const bmh_read_t *reads, const bmh_chain_v *chains,
-                        const uint8_t *const *skip, bmh_alnreg_v *regs);
+                        const bmh_read_t *reads, const bmh_chain_v *chains, bmh_chain_pre_fn pre,
+                        void *pre_user, bmh_alnreg_v *regs);
 
 /* Counters of the last bmh_chain2aln_batch call (for the bench / logs). */
 typedef struct bmh_driver_stats {

@@ -1,0 +1,131 @@
+"""GPU parity tests proper: the HIP path, called through the C-ABI (ctypes ->
+libbwamem_hip.so), must be BIT-EXACT against the CPU oracle on the same seeded
+inputs.  Integer work: the tolerance is zero."""
+import numpy as np
+import pytest
+
+import kswgen
+import kswlib
+from __graft_entry__ import load_package
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return load_package()
+
+
+@pytest.fixture(scope="module")
+def ctx(pkg):
+    c = pkg.Context(0, kswlib.make_params())
+    yield c
+    c.close()
+
+
+def _cmp_ext(ctx, p, pool, tasks):
+    ctx.set_params(p)
+    got = ctx.extend_batch(pool, tasks)
+    want, _ = kswlib.orc_extend_batch(p, pool, tasks)
+    bad = np.nonzero(got != want)[0]
+    assert len(bad) == 0, f"{len(bad)} mismatches; first task {bad[0]}: {tasks[bad[0]]} gpu={got[bad[0]]} oracle={want[bad[0]]}"
+
+
+def test_extend_realistic_150bp(ctx):
+    rng = np.random.default_rng(201)
+    pool, tasks = kswgen.gen_ext_realistic(rng, 4000)
+    _cmp_ext(ctx, kswlib.make_params(), pool, tasks)
+
+
+def test_extend_hard_100_300bp(ctx):
+    rng = np.random.default_rng(202)
+    pool, tasks = kswgen.gen_ext_realistic(rng, 3000, read_len=(100, 300), hard=True)
+    _cmp_ext(ctx, kswlib.make_params(), pool, tasks)
+
+
+def test_extend_long_queries_multichunk(ctx):
+    """qlen up to 1000: several 64-column chunks per row, band retry widths, long targets (>256 rows)."""
+    rng = np.random.default_rng(203)
+    pool, tasks = kswgen.gen_ext_realistic(rng, 300, read_len=(600, 1100), hard=True, w=100)
+    _cmp_ext(ctx, kswlib.make_params(), pool, tasks)
+    pool, tasks = kswgen.gen_ext_realistic(rng, 200, read_len=(600, 1100), hard=False, w=200)
+    _cmp_ext(ctx, kswlib.make_params(w=200, zdrop=0), pool, tasks)
+
+
+def test_extend_fuzz_param_sets(ctx):
+    rng = np.random.default_rng(204)
+    for p in kswgen.fuzz_param_sets(rng, 40):
+        pool, tasks = kswgen.gen_ext_fuzz(rng, 400, p)
+        _cmp_ext(ctx, p, pool, tasks)
+
+
+def test_extend_empty_and_tiny_batches(ctx):
+    p = kswlib.make_params()
+    ctx.set_params(p)
+    assert len(ctx.extend_batch(np.zeros(8, np.uint8), np.zeros(0, kswlib.EXT_TASK))) == 0
+    rng = np.random.default_rng(205)
+    pool, tasks = kswgen.gen_ext_realistic(rng, 1)
+    _cmp_ext(ctx, p, pool, tasks)
+
+
+def test_extend_rejects_out_of_range(ctx, pkg):
+    p = kswlib.make_params()
+    ctx.set_params(p)
+    pool = np.zeros(70000, np.uint8)
+    t = np.zeros(1, kswlib.EXT_TASK)
+    t["qlen"], t["tlen"], t["h0"], t["w"], t["t_off"] = 40000, 10, 100, 100, 40000  # 40000*1+100 > 32000
+    with pytest.raises(pkg.BmhError) as e:
+        ctx.extend_batch(pool, t)
+    assert e.value.code == pkg.BMH_E_RANGE
+    t["qlen"], t["q_off"] = 10, 69999  # reads past the pool
+    with pytest.raises(pkg.BmhError) as e:
+        ctx.extend_batch(pool, t)
+    assert e.value.code == pkg.BMH_E_ARG
+    with pytest.raises(pkg.BmhError):
+        ctx.set_params(kswlib.make_params(e_ins=0))
+
+
+def test_extend_sharded_two_contexts_one_device(ctx, pkg):
+    """The static multi-GPU split (one context per device) exercised with 2 contexts on GPU 0."""
+    p = kswlib.make_params()
+    c2 = pkg.Context(0, p)
+    ctx.set_params(p)
+    rng = np.random.default_rng(206)
+    pool, tasks = kswgen.gen_ext_realistic(rng, 1001)
+    got = pkg.extend_batch_sharded([ctx, c2], pool, tasks)
+    want, _ = kswlib.orc_extend_batch(p, pool, tasks)
+    assert (got == want).all()
+    c2.close()
+
+
+def _cmp_glb(ctx, p, pool, tasks, words):
+    ctx.set_params(p)
+    res, cig = ctx.global_batch(pool, tasks, words)
+    ores, ocig = kswlib.orc_global_batch(p, pool, tasks)
+    bad = np.nonzero(res != ores)[0]
+    assert len(bad) == 0, f"first mismatch {bad[0]}: {tasks[bad[0]]} gpu={res[bad[0]]} oracle={ores[bad[0]]}"
+    for k, (t, r, oc) in enumerate(zip(tasks, res, ocig)):
+        got = cig[int(t["cigar_off"]): int(t["cigar_off"]) + int(r["n_cigar"])]
+        assert np.array_equal(got, oc), f"task {k}: cigar gpu={got} oracle={oc}"
+
+
+def test_global_realistic(ctx):
+    rng = np.random.default_rng(207)
+    pool, tasks, words = kswgen.gen_glb_realistic(rng, 1500)
+    _cmp_glb(ctx, kswlib.make_params(), pool, tasks, words)
+    pool, tasks, words = kswgen.gen_glb_realistic(rng, 800, read_len=(100, 300), hard=True)
+    _cmp_glb(ctx, kswlib.make_params(), pool, tasks, words)
+
+
+def test_global_long_hbm_scratch(ctx):
+    """Direction matrix too large for LDS -> HBM scratch slab variant of the kernel."""
+    rng = np.random.default_rng(208)
+    pool, tasks, words = kswgen.gen_glb_realistic(rng, 60, read_len=(900, 1500), hard=True)
+    _cmp_glb(ctx, kswlib.make_params(), pool, tasks, words)
+
+
+def test_global_fuzz_param_sets(ctx):
+    rng = np.random.default_rng(209)
+    for p in kswgen.fuzz_param_sets(rng, 25):
+        pool, tasks, words = kswgen.gen_glb_fuzz(rng, 200)
+        _cmp_glb(ctx, p, pool, tasks, words)
