@@ -122,7 +122,7 @@ int bmh_ctx_destroy(bmh_ctx_t *ctx)
 	(void)hipSetDevice(ctx->device);
 	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 	free_buf(ctx->d_pool), free_buf(ctx->d_tasks), free_buf(ctx->d_res), free_buf(ctx->d_order);
-	free_buf(ctx->d_cigar), free_buf(ctx->d_scratch);
+	free_buf(ctx->d_cigar), free_buf(ctx->d_scratch), free_buf(ctx->d_bins);
 	if (ctx->d_err) (void)hipFree(ctx->d_err);
 	if (ctx->h_err) (void)hipHostFree(ctx->h_err);
 	if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -144,7 +144,9 @@ int bmh_ctx_set_params(bmh_ctx_t *ctx, const bmh_params_t *p)
 	DevParams &d = ctx->dev;
 	d.o_del = p->o_del, d.e_del = p->e_del, d.o_ins = p->o_ins, d.e_ins = p->e_ins, d.zdrop = p->zdrop;
 	d.max_mat = 0; // ksw.c:399-400 starts the maximum at 0
-	for (int i = 0; i < 25; ++i) d.max_mat = std::max(d.max_mat, (int)p->mat[i]);
+	int mn = 0;
+	for (int i = 0; i < 25; ++i) d.max_mat = std::max(d.max_mat, (int)p->mat[i]), mn = std::min(mn, (int)p->mat[i]);
+	d.bias = -mn;
 	uint8_t bytes[28] = {0};
 	memcpy(bytes, p->mat, 25);
 	memcpy(d.matw, bytes, 28);

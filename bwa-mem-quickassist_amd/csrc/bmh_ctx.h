@@ -21,6 +21,8 @@ struct bmh_ctx {
 	int qcap = 512; // query-length capacity used to size the LDS kernel's window state for *_device calls
 	// device workspaces of the host-buffer entry points
 	DevBuf d_pool, d_tasks, d_res, d_order, d_cigar, d_scratch;
+	DevBuf d_bins; // per-launch bin lists of the extension dispatcher: 4 counters + 4 x n task indices
+	int force_kernel = 0; // 0 = dispatch by length; 1 = LDS kernel only (debug/A-B, env BMH_FORCE_LDS)
 	bool pool_resident = false; // d_pool holds a pool uploaded by bmh_upload_pool()
 	size_t pool_bytes = 0;
 	int *d_err = nullptr; // device error flag (BMH_E_* or 0)
@@ -45,8 +47,17 @@ int ensure(bmh_ctx *ctx, DevBuf &b, size_t bytes);
 	} while (0)
 
 // kernel launchers (defined next to the kernels)
+// grid cap of the extension kernels: enough blocks to keep every wave slot refilled (256 CUs x 32 waves x 4),
+// each block walks its bin with a grid stride
+constexpr long long kPersistentGrid = 256LL * 32 * 4;
+
+// dispatcher: classifies the tasks by query length on the device and runs each bin on its kernel
 int launch_extend(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
                   bmh_ext_result_t *d_res, const uint32_t *d_order, int qmax);
+int launch_extend_lds(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
+                      bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, int qmax);
+int launch_extend_reg(bmh_ctx *ctx, int ns, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
+                      bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count);
 int launch_global(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_glb_task_t *d_tasks, int64_t n,
                   bmh_glb_result_t *d_res, uint32_t *d_cigar, const uint32_t *d_order, int qmax, int tmax,
                   int wmax);

@@ -12,6 +12,7 @@ namespace bmh {
 struct DevParams {
 	int o_del, e_del, o_ins, e_ins, zdrop;
 	int max_mat;      // max entry of mat[] (ksw.c:398-400), precomputed on the host
+	int bias;         // -min(mat[]) floored at 0: profile bytes are stored as score+bias (unsigned)
 	uint32_t matw[7]; // mat[25] as bytes, little endian, padded to 28
 };
 

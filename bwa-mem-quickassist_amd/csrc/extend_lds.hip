@@ -34,7 +34,8 @@ __device__ __forceinline__ void store_result(bmh_ext_result_t *o, int score, int
 
 __global__ __launch_bounds__(64) void extend_lds_kernel(const uint8_t *__restrict__ pool,
                                                         const bmh_ext_task_t *__restrict__ tasks,
-                                                        const uint32_t *__restrict__ order, long long n,
+                                                        const uint32_t *__restrict__ order,
+                                                        const uint32_t *__restrict__ count, long long n,
                                                         bmh_ext_result_t *__restrict__ out, DevParams P,
                                                         int qcap, int *__restrict__ err_flag)
 {
@@ -48,6 +49,7 @@ __global__ __launch_bounds__(64) void extend_lds_kernel(const uint8_t *__restric
 
 	if (lane < 25) smat[lane] = (int8_t)mat_at(P, lane);
 
+	if (count) n = *count; // bin size produced on the device by classify_kernel
 	for (long long slot = blockIdx.x; slot < n; slot += gridDim.x) {
 		const uint32_t idx = order ? order[slot] : (uint32_t)slot;
 		const uint4 *tp = (const uint4 *)(tasks + idx);
@@ -176,23 +178,18 @@ __global__ __launch_bounds__(64) void extend_lds_kernel(const uint8_t *__restric
 	}
 }
 
-// ---- launcher ---------------------------------------------------------------------------
-int launch_extend(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
-                  bmh_ext_result_t *d_res, const uint32_t *d_order, int qmax)
+// ---- launcher: every task listed in d_order[0..*d_count) (or 0..n when d_count is null)
+int launch_extend_lds(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
+                      bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, int qmax)
 {
 	if (n <= 0) return BMH_OK;
 	const int qcap = (qmax + 63) & ~63;
 	const size_t shmem = (((size_t)4 * (qcap + 2) + 15) & ~(size_t)15) + (size_t)8 * qcap + 32;
 	if (shmem > 160 * 1024) return BMH_E_RANGE;
-	const long long grid = n < (1LL << 30) ? n : (1LL << 30);
-	if (ctx->timing) BMH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+	const long long grid = n < kPersistentGrid ? n : kPersistentGrid;
 	hipLaunchKernelGGL(extend_lds_kernel, dim3((unsigned)grid), dim3(64), shmem, ctx->stream, d_pool, d_tasks, d_order,
-	                   (long long)n, d_res, ctx->dev, qcap, ctx->d_err);
+	                   d_count, (long long)n, d_res, ctx->dev, qcap, ctx->d_err);
 	BMH_HIP(ctx, hipGetLastError());
-	if (ctx->timing) {
-		BMH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-		ctx->ev_valid = true;
-	}
 	return BMH_OK;
 }
 
