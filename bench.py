@@ -54,11 +54,12 @@ def main():
     pkg = load_package()
     import importlib
     tg = importlib.import_module("bwa_mem_quickassist_amd.taskgen")
+    sh = importlib.import_module("bwa_mem_quickassist_amd.shard")
 
     # ---- workload: this rank's shard (distinct seed per rank, same size: weak scaling)
     params = kswlib.make_params()  # bwa mem defaults, reference bwamem.c:45-75
     t0 = time.time()
-    pool, tasks, tread = tg.generate(params, args.reads, args.workload, seed=7 + 1000 * rank)
+    pool, tasks, tread = tg.generate(params, args.reads, args.workload, seed=sh.shard_seed(7, rank))
     n_tasks = len(tasks)
     n_reads_used = int(len(np.unique(tread)))
     gen_s = time.time() - t0
@@ -100,14 +101,7 @@ def main():
     ctx.sync()  # surfaces any BMH_E_RANGE flagged by the kernel
     if world > 1:
         dist.barrier()
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        tot = torch.tensor([n_reads_used, n_tasks], dtype=torch.float64, device=dev)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        reads_all, tasks_all = float(tot[0].item()), float(tot[1].item())
-    else:
-        reads_all, tasks_all = float(n_reads_used), float(n_tasks)
+    elapsed, reads_all, tasks_all = sh.reduce_report(elapsed, n_reads_used, n_tasks, dev)
 
     # ---- parity spot-check + CPU baseline (untimed w.r.t. the GPU figure)
     res = d_res.cpu().numpy().view(pkg.EXT_RES)

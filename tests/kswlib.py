@@ -210,3 +210,63 @@ def orc_global_batch(p, pool, tasks):
     def call(ql, q, tl, t, w, n, cg):
         return lib.orc_global(C.byref(sc), ql, q, tl, t, w, n, cg)
     return _global_generic(call, pool, tasks)
+
+
+# ---- driver level ------------------------------------------------------------
+class _CSeedChain(C.Structure):  # bmh_chain_t == mem_chain_t
+    _fields_ = [("n", C.c_int32), ("m", C.c_int32), ("pos", C.c_int64), ("seeds", C.c_void_p)]
+
+
+class _CAlnregV(C.Structure):
+    _fields_ = [("n", C.c_size_t), ("m", C.c_size_t), ("a", C.c_void_p)]
+
+
+def orc_chain2aln_reads(p, l_pac, pac, reads, chains):
+    """OUR restatement of mem_chain2aln, read by read, chain by chain (shared region vector per read)."""
+    lib = load_oracle()
+    pp = np.ascontiguousarray(np.asarray(p, dtype=PARAMS).reshape(()))
+    pac = np.ascontiguousarray(pac, dtype=np.uint8)
+    out = []
+    for seq, chs in zip(reads, chains):
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        regs = _CAlnregV(0, 0, None)
+        for sd in chs:
+            sd = np.ascontiguousarray(sd, dtype=SEED)
+            c = _CSeedChain(len(sd), len(sd), int(sd["rbeg"][0]) if len(sd) else 0, sd.ctypes.data)
+            lib.orc_chain2aln(pp.ctypes.data_as(C.c_void_p), C.c_int64(l_pac), pac.ctypes.data_as(C.c_void_p),
+                              C.c_int(len(seq)), seq.ctypes.data_as(C.c_void_p), C.byref(c), C.byref(regs), None)
+        a = np.zeros(regs.n, dtype=ALNREG)
+        if regs.n:
+            C.memmove(a.ctypes.data, regs.a, regs.n * ALNREG.itemsize)
+        if regs.a:
+            _libc.free(regs.a)
+        out.append(a)
+    return out
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN_DIR, name), allow_pickle=False)
+
+
+def golden_chain2aln_groups():
+    """Yields (params, l_pac, pac, reads, chains, expected_regs) per parameter set of chain2aln_golden.npz."""
+    g = load_golden("chain2aln_golden.npz")
+    l_pac, pac = int(g["l_pac"]), g["pac"]
+    ro, rp = g["read_off"], g["read_pool"]
+    nch, nsd, seeds = g["read_nchains"], g["chain_nseeds"], g["seeds"]
+    nrg, regs = g["read_nregs"], g["regs"]
+    ci = si = gi = 0
+    per_group = {}
+    for r in range(len(nch)):
+        read = rp[ro[r]:ro[r + 1]]
+        chs = []
+        for _ in range(nch[r]):
+            chs.append(seeds[si:si + nsd[ci]])
+            si += nsd[ci]
+            ci += 1
+        exp = regs[gi:gi + nrg[r]]
+        gi += nrg[r]
+        per_group.setdefault(int(g["read_group"][r]), []).append((read, chs, exp))
+    for k in sorted(per_group):
+        items = per_group[k]
+        yield g["params"][k], l_pac, pac, [x[0] for x in items], [x[1] for x in items], [x[2] for x in items]

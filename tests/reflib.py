@@ -1,0 +1,145 @@
+"""ctypes access to the REFERENCE compiled by oracle/Makefile (oracle/_ref/libbwa_ref.so):
+index loading, seeding+chaining and the reference's own mem_chain2aln.  Checker-side only;
+used by tools/make_golden.py and by the `ref`-gated tests.  Struct mirrors cite the reference."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+import kswlib
+
+REF_BWA = os.path.join(kswlib.REF_DIR, "bwa")
+REF_LIB = os.path.join(kswlib.REF_DIR, "libbwa_ref.so")
+
+
+def have_ref_bwa():
+    return os.path.exists(REF_BWA) and os.path.exists(REF_LIB)
+
+
+class MemOpt(C.Structure):  # fork's mem_opt_t, bwamem.h:21-48
+    _fields_ = [(n, C.c_int) for n in ("a", "b", "o_del", "e_del", "o_ins", "e_ins", "pen_unpaired", "pen_clip5",
+                                        "pen_clip3", "w", "zdrop", "T", "flag", "min_seed_len")] + \
+               [("split_factor", C.c_float)] + \
+               [(n, C.c_int) for n in ("split_width", "max_occ", "max_chain_gap", "n_threads", "batch_size",
+                                        "chunk_size")] + \
+               [(n, C.c_float) for n in ("mask_level", "chain_drop_ratio", "mask_level_redun", "mapQ_coef_len")] + \
+               [(n, C.c_int) for n in ("mapQ_coef_fac", "max_ins", "max_matesw")] + [("mat", C.c_int8 * 25)]
+
+
+class Seed(C.Structure):  # mem_seed_t, bwamem.c:168-171
+    _fields_ = [("rbeg", C.c_int64), ("qbeg", C.c_int32), ("len", C.c_int32)]
+
+
+class Chain(C.Structure):  # mem_chain_t, bwamem.c:173-177
+    _fields_ = [("n", C.c_int), ("m", C.c_int), ("pos", C.c_int64), ("seeds", C.POINTER(Seed))]
+
+
+class ChainV(C.Structure):  # mem_chain_v, bwamem.c:179
+    _fields_ = [("n", C.c_size_t), ("m", C.c_size_t), ("a", C.POINTER(Chain))]
+
+
+class AlnregV(C.Structure):  # mem_alnreg_v, bwamem.h:64
+    _fields_ = [("n", C.c_size_t), ("m", C.c_size_t), ("a", C.c_void_p)]
+
+
+class BntSeqHead(C.Structure):  # first field of bntseq_t, bntseq.h:53
+    _fields_ = [("l_pac", C.c_int64)]
+
+
+class BwaIdx(C.Structure):  # bwaidx_t, bwa.h:13-17
+    _fields_ = [("bwt", C.c_void_p), ("bns", C.POINTER(BntSeqHead)), ("pac", C.POINTER(C.c_uint8))]
+
+
+_lib = None
+_libc = C.CDLL(None)
+_libc.free.argtypes = [C.c_void_p]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(REF_LIB)
+        L.mem_opt_init.restype = C.POINTER(MemOpt)
+        L.bwa_idx_load.restype = C.POINTER(BwaIdx)
+        L.bwa_idx_load.argtypes = [C.c_char_p, C.c_int]
+        L.mem_chain.restype = ChainV
+        L.mem_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
+        L.mem_chain_flt.restype = C.c_int
+        L.mem_chain_flt.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.mem_chain2aln.restype = None
+        L.mem_chain2aln.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.bwa_fill_scmat.argtypes = [C.c_int, C.c_int, C.c_void_p]
+        C.c_int.in_dll(L, "bwa_verbose").value = 1
+        _lib = L
+    return _lib
+
+
+def write_fasta(path, name, codes):
+    with open(path, "w") as f:
+        f.write(f">{name}\n")
+        s = "".join("ACGT"[c] for c in codes)
+        for i in range(0, len(s), 80):
+            f.write(s[i:i + 80] + "\n")
+
+
+def write_fastq(path, reads, prefix="r"):
+    with open(path, "w") as f:
+        for i, r in enumerate(reads):
+            f.write(f"@{prefix}{i}\n" + "".join("ACGTN"[c] for c in r) + "\n+\n" + "I" * len(r) + "\n")
+
+
+def build_index(fasta):
+    subprocess.run([REF_BWA, "index", fasta], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+
+def opt_from_params(p):
+    """mem_opt_t with the hot-path fields taken from a kswlib.PARAMS record."""
+    L = lib()
+    o = L.mem_opt_init()
+    for k in ("a", "o_del", "e_del", "o_ins", "e_ins", "w", "zdrop", "pen_clip5", "pen_clip3"):
+        setattr(o.contents, k, int(p[k]))
+    for i in range(25):
+        o.contents.mat[i] = int(p["mat"][i])
+    return o
+
+
+def chains_and_regs(idx, opt, reads, run_chain2aln=True):
+    """Per read: the reference's chains after mem_chain + mem_chain_flt (bwamem.c:1131-1132) and, if asked,
+    the regions the reference's OWN mem_chain2aln appends for them (bwamem.c:1141, shared vector)."""
+    L = lib()
+    l_pac = idx.contents.bns.contents.l_pac
+    all_chains, all_regs = [], []
+    for r in reads:
+        seq = np.ascontiguousarray(r, dtype=np.uint8)
+        cv = L.mem_chain(opt, idx.contents.bwt, l_pac, len(seq), seq.ctypes.data_as(C.c_void_p))
+        n = L.mem_chain_flt(opt, int(cv.n), cv.a)
+        chains = []
+        regs = AlnregV(0, 0, None)
+        for ci in range(n):
+            c = cv.a[ci]
+            sd = np.zeros(c.n, dtype=kswlib.SEED)
+            for k in range(c.n):
+                sd[k] = (c.seeds[k].rbeg, c.seeds[k].qbeg, c.seeds[k].len)
+            chains.append(sd)
+            if run_chain2aln:
+                L.mem_chain2aln(opt, l_pac, idx.contents.pac, len(seq), seq.ctypes.data_as(C.c_void_p),
+                                C.byref(cv.a[ci]), C.byref(regs))
+        out = np.zeros(regs.n, dtype=kswlib.ALNREG)
+        if regs.n:
+            C.memmove(out.ctypes.data, regs.a, regs.n * kswlib.ALNREG.itemsize)
+        if regs.a:
+            _libc.free(regs.a)
+        for ci in range(n):  # mem_chain_flt already freed the seeds of the chains it dropped (bwamem.c:362-368)
+            _libc.free(C.cast(cv.a[ci].seeds, C.c_void_p))
+        if cv.a:
+            _libc.free(C.cast(cv.a, C.c_void_p))
+        all_chains.append(chains)
+        all_regs.append(out)
+    return all_chains, all_regs
+
+
+def pac_of(idx):
+    l_pac = idx.contents.bns.contents.l_pac
+    n = l_pac // 4 + 1
+    return int(l_pac), np.ctypeslib.as_array(idx.contents.pac, shape=(n,)).copy()

@@ -1,0 +1,99 @@
+"""Whole-pipeline DUT/REF parity -- the reference author's own acceptance test (pipeline.sh vs
+pipeline_ref.sh: SAM of the fork == SAM of stock).
+
+REF = the reference compiled by oracle/Makefile (oracle/_ref/bwa), untouched.
+DUT = the same binary with libbwamem_hip_dropin.so LD_PRELOADed: phase 1 goes through the fork's
+      batching seam mem_align1_core_batched -> bmh_chain2aln_batch (GPU extension kernels, one
+      context per host thread), and every ksw_global2 of phase 2 is a per-call GPU drop-in.
+SAM must be byte-identical except the @PG header line.  Runs first in the session (file name) so
+the parent process is GPU-clean when it starts the child processes."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+import kswgen
+import kswlib
+import reflib
+from __graft_entry__ import load_package
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not reflib.have_ref_bwa(), reason="oracle/_ref not built")]
+
+
+def _sim_reads(rng, ref, n, L, hard, pair=False):
+    r1, r2 = [], []
+    for _ in range(n):
+        ins = int(rng.integers(250, 450)) if pair else L
+        pos = int(rng.integers(0, len(ref) - ins - 60))
+        frag = ref[pos:pos + ins + 40]
+        sub, ind, mx = (0.03, 0.008, 10) if hard else (0.02, 0.0025, 1)
+        a = kswgen.mutate(rng, frag[:L + 30], sub, ind, ind, mx)[:L]
+        if hard and rng.random() < 0.25:
+            cut = int(rng.integers(40, L - 20))
+            p2 = int(rng.integers(0, len(ref) - L))
+            a = np.concatenate([a[:cut], ref[p2:p2 + L - cut]])
+        a = a.copy()
+        if hard:
+            a[rng.random(len(a)) < 0.01] = 4
+        if pair:
+            b = kswgen.mutate(rng, frag[ins - L:ins + 30], sub, ind, ind, mx)[:L]
+            b = (3 - b[::-1]).astype(np.uint8)
+            r1.append(a), r2.append(b)
+        else:
+            if rng.random() < 0.5:
+                a = np.where(a[::-1] > 3, 4, 3 - a[::-1]).astype(np.uint8)
+            r1.append(a)
+    return r1, r2
+
+
+@pytest.fixture(scope="module")
+def genome():
+    rng = np.random.default_rng(424242)
+    tmp = tempfile.mkdtemp(prefix="bmh_sam_")
+    ref = kswgen.rand_seq(rng, 400000)
+    for _ in range(30):  # planted diverged repeats -> multi-chain reads, secondary hits, mapQ ties
+        a, b, L = int(rng.integers(0, 380000)), int(rng.integers(0, 380000)), int(rng.integers(200, 800))
+        ref[b:b + L] = kswgen.mutate(rng, ref[a:a + L + 20], 0.02, 0.002, 0.002, 2)[:L]
+    fa = os.path.join(tmp, "ref.fa")
+    reflib.write_fasta(fa, "synth", ref)
+    reflib.build_index(fa)
+    return rng, tmp, fa, ref
+
+
+def _run(fa, fqs, out, extra, preload):
+    env = dict(os.environ)
+    if preload:
+        env["LD_PRELOAD"] = load_package().DROPIN_PATH
+    with open(out, "w") as f:
+        subprocess.run([reflib.REF_BWA, "mem", "-v", "1"] + extra + [fa] + fqs, check=True, stdout=f,
+                       stderr=subprocess.DEVNULL, env=env, timeout=600)
+    return [l for l in open(out) if not l.startswith("@PG")]
+
+
+@pytest.mark.parametrize("extra", [["-t", "4", "-b", "512"], ["-t", "2", "-b", "64", "-w", "10", "-d", "30"],
+                                   ["-t", "3", "-b", "1000", "-A", "2", "-B", "6", "-O", "8,6", "-E", "2,3"]])
+def test_se_sam_identical(genome, extra):
+    rng, tmp, fa, ref = genome
+    reads = _sim_reads(rng, ref, 1500, 150, False)[0] + _sim_reads(rng, ref, 700, 250, True)[0] + \
+        _sim_reads(rng, ref, 300, 101, True)[0]
+    fq = os.path.join(tmp, "se.fq")
+    reflib.write_fastq(fq, reads)
+    ref_sam = _run(fa, [fq], os.path.join(tmp, "ref.sam"), extra, False)
+    dut_sam = _run(fa, [fq], os.path.join(tmp, "dut.sam"), extra, True)
+    assert len(ref_sam) > len(reads)
+    assert ref_sam == dut_sam
+
+
+def test_pe_sam_identical(genome):
+    rng, tmp, fa, ref = genome
+    r1, r2 = _sim_reads(rng, ref, 1200, 150, False, pair=True)
+    f1, f2 = os.path.join(tmp, "pe_1.fq"), os.path.join(tmp, "pe_2.fq")
+    reflib.write_fastq(f1, r1, "p")
+    reflib.write_fastq(f2, r2, "p")
+    extra = ["-t", "4", "-b", "400"]
+    ref_sam = _run(fa, [f1, f2], os.path.join(tmp, "ref_pe.sam"), extra, False)
+    dut_sam = _run(fa, [f1, f2], os.path.join(tmp, "dut_pe.sam"), extra, True)
+    assert len(ref_sam) >= 2400
+    assert ref_sam == dut_sam

@@ -1,0 +1,67 @@
+"""The N>1 path of bench.py on CPU: two processes, gloo backend.  Checks that ranks get distinct,
+reproducible shards of the synthetic workload, that the report reduction is max(time)/sum(units),
+and that the contiguous split used by bmh_extend_batch_sharded tiles the batch exactly."""
+import os
+import sys
+
+import numpy as np
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import importlib
+    import torch.distributed as dist
+    import kswlib
+    from __graft_entry__ import load_package
+    load_package()
+    tg = importlib.import_module("bwa_mem_quickassist_amd.taskgen")
+    sh = importlib.import_module("bwa_mem_quickassist_amd.shard")
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    p = kswlib.make_params()
+    pool, tasks, tread = tg.generate(p, 3000, "150bp", seed=sh.shard_seed(7, rank))
+    res, cells = kswlib.orc_extend_batch(p, pool, tasks[:500])  # the CPU checker stands in for the GPU here
+    dist.barrier()
+    el, reads, ntask = sh.reduce_report(0.5 + rank, len(np.unique(tread)), len(tasks))
+    q.put((rank, int(pool[:4096].astype(np.int64).sum()), len(tasks), int(res["score"].sum()), el, reads, ntask))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_shards_and_report():
+    from __graft_entry__ import build, load_package
+    pkg = load_package()
+    if not os.path.exists(os.path.join(os.path.dirname(pkg.LIB_PATH), "libbmh_taskgen.so")):
+        build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, sum0, n0, sc0, el0, reads0, t0), (r1, sum1, n1, sc1, el1, reads1, t1) = out
+    assert sum0 != sum1 and sc0 != sc1            # different shards
+    assert el0 == el1 == 1.5                      # max over ranks
+    assert t0 == t1 == n0 + n1                    # sum over ranks
+    assert reads0 == reads1 and 5000 < reads0 <= 6000
+
+
+def test_contiguous_split_tiles_the_batch():
+    import importlib
+    from __graft_entry__ import load_package
+    load_package()
+    sh = importlib.import_module("bwa_mem_quickassist_amd.shard")
+    for n in (0, 1, 7, 1000, 1480968):
+        for w in (1, 2, 4, 8):
+            r = sh.shard_ranges(n, w)
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+            assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
