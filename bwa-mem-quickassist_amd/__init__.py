@@ -88,6 +88,7 @@ def lib():
         L.bmh_ctx_set_qcap.argtypes = [C.c_void_p, C.c_int]
         L.bmh_set_kernel_timing.argtypes = [C.c_void_p, C.c_int]
         L.bmh_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.bmh_last_extend_bin_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.bmh_upload_pool.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.bmh_extend_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int64, C.c_void_p]
         L.bmh_extend_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
@@ -158,6 +159,11 @@ class Context:
         ms = C.c_float(-1)
         self._check(lib().bmh_last_kernel_ms(self._h, C.byref(ms)))
         return ms.value
+
+    def last_extend_bin_ms(self):
+        ms = (C.c_float * 4)()
+        self._check(lib().bmh_last_extend_bin_ms(self._h, ms))
+        return [float(x) for x in ms]
 
     # ---- L2, host buffers
     def extend_batch(self, pool, tasks):

@@ -106,7 +106,10 @@ int bmh_ctx_create(bmh_ctx_t **out, int device)
 	if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess ||
 	    (e = hipMalloc((void **)&ctx->d_err, sizeof(int))) != hipSuccess || (e = hipMemset(ctx->d_err, 0, sizeof(int))) != hipSuccess ||
 	    (e = hipHostMalloc((void **)&ctx->h_err, sizeof(int), hipHostMallocDefault)) != hipSuccess ||
-	    (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess) {
+	    (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess ||
+	    (e = hipEventCreate(&ctx->ev_bin[0])) != hipSuccess || (e = hipEventCreate(&ctx->ev_bin[1])) != hipSuccess ||
+	    (e = hipEventCreate(&ctx->ev_bin[2])) != hipSuccess || (e = hipEventCreate(&ctx->ev_bin[3])) != hipSuccess ||
+	    (e = hipEventCreate(&ctx->ev_bin[4])) != hipSuccess) {
 		fprintf(stderr, "[bwamem_hip] context creation failed: %s\n", hipGetErrorString(e));
 		bmh_ctx_destroy(ctx);
 		return BMH_E_NODEVICE;
@@ -127,6 +130,8 @@ int bmh_ctx_destroy(bmh_ctx_t *ctx)
 	if (ctx->h_err) (void)hipHostFree(ctx->h_err);
 	if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
 	if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+	for (int b = 0; b < 5; ++b)
+		if (ctx->ev_bin[b]) (void)hipEventDestroy(ctx->ev_bin[b]);
 	if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
 	delete ctx;
 	return BMH_OK;
@@ -191,6 +196,16 @@ int bmh_last_kernel_ms(bmh_ctx_t *ctx, float *ms)
 	if (!ctx->ev_valid) return BMH_OK;
 	BMH_HIP(ctx, hipEventSynchronize(ctx->ev1));
 	BMH_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+	return BMH_OK;
+}
+
+int bmh_last_extend_bin_ms(bmh_ctx_t *ctx, float ms[4])
+{
+	if (!ctx || !ms) return BMH_E_ARG;
+	for (int b = 0; b < 4; ++b) ms[b] = -1.f;
+	if (!ctx->ev_bin_valid) return BMH_OK;
+	BMH_HIP(ctx, hipEventSynchronize(ctx->ev_bin[4]));
+	for (int b = 0; b < 4; ++b) BMH_HIP(ctx, hipEventElapsedTime(&ms[b], ctx->ev_bin[b], ctx->ev_bin[b + 1]));
 	return BMH_OK;
 }
 

@@ -31,6 +31,8 @@ struct bmh_ctx {
 	bool timing = false;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	bool ev_valid = false;
+	hipEvent_t ev_bin[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // boundaries of the 4 extension bins
+	bool ev_bin_valid = false;
 	std::string last_error;
 	bmh_driver_stats_t dstats{};
 };

@@ -58,20 +58,24 @@ int launch_extend(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_t
 	hipLaunchKernelGGL(classify_kernel, dim3((unsigned)cg), dim3(256), 0, ctx->stream, d_tasks, d_order, (long long)n, counts,
 	                   lists, reg_ok ? 1 : 0);
 	BMH_HIP(ctx, hipGetLastError());
-	if (ctx->timing) BMH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-	if (reg_ok) {
-		if ((rc = launch_extend_reg(ctx, 1, d_pool, d_tasks, n, d_res, lists, counts + 0))) return rc;
-		if (qmax > 64 && (rc = launch_extend_reg(ctx, 2, d_pool, d_tasks, n, d_res, lists + (size_t)n, counts + 1))) return rc;
-		if (qmax > 128 && (rc = launch_extend_reg(ctx, 4, d_pool, d_tasks, n, d_res, lists + 2 * (size_t)n, counts + 2)))
-			return rc;
-	}
+	const bool tm = ctx->timing;
+	if (tm) BMH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+	if (tm) BMH_HIP(ctx, hipEventRecord(ctx->ev_bin[0], ctx->stream));
+	if (reg_ok && (rc = launch_extend_reg(ctx, 1, d_pool, d_tasks, n, d_res, lists, counts + 0))) return rc;
+	if (tm) BMH_HIP(ctx, hipEventRecord(ctx->ev_bin[1], ctx->stream));
+	if (reg_ok && qmax > 64 && (rc = launch_extend_reg(ctx, 2, d_pool, d_tasks, n, d_res, lists + (size_t)n, counts + 1))) return rc;
+	if (tm) BMH_HIP(ctx, hipEventRecord(ctx->ev_bin[2], ctx->stream));
+	if (reg_ok && qmax > 128 && (rc = launch_extend_reg(ctx, 4, d_pool, d_tasks, n, d_res, lists + 2 * (size_t)n, counts + 2)))
+		return rc;
+	if (tm) BMH_HIP(ctx, hipEventRecord(ctx->ev_bin[3], ctx->stream));
 	// bin 3 always gets a launch: it also holds qlen == 0 tasks; an empty bin costs one idle grid
 	if ((rc = launch_extend_lds(ctx, d_pool, d_tasks, reg_ok && qmax <= 256 ? 64 : n, d_res, lists + 3 * (size_t)n, counts + 3,
 	                            qmax)))
 		return rc;
-	if (ctx->timing) {
+	if (tm) {
+		BMH_HIP(ctx, hipEventRecord(ctx->ev_bin[4], ctx->stream));
 		BMH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-		ctx->ev_valid = true;
+		ctx->ev_valid = ctx->ev_bin_valid = true;
 	}
 	return BMH_OK;
 }
