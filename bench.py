@@ -136,13 +136,24 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = reads_all * args.steps / elapsed
         # dominant kernel = the length bin that takes the most time; its algorithmic bytes / its duration
-        bin_names = ["extend_reg_kernel<1> (qlen<=64)", "extend_reg_kernel<2> (qlen<=128)",
-                     "extend_reg_kernel<4> (qlen<=256)", "extend_lds_kernel (longer)"]
+        mode = os.environ.get("BMH_EXT_MODE", "lane")
+        fam = {"lane": ["extend_lane_kernel<32> (qlen<=32, 64 tasks/wave)", "extend_lane_kernel<64> (qlen<=64, 64 tasks/wave)",
+                        "extend_lane_kernel<128> (qlen<=128, 64 tasks/wave)"],
+               "grp": ["extend_grp_kernel<2> (qlen<=32, 4 tasks/wave)", "extend_grp_kernel<4> (qlen<=64, 4 tasks/wave)",
+                       "extend_grp_kernel<8> (qlen<=128, 4 tasks/wave)"],
+               "reg": ["extend_reg_kernel<1> (qlen<=32)", "extend_reg_kernel<1> (qlen<=64)", "extend_reg_kernel<2> (qlen<=128)"],
+               "lds": ["-", "-", "-"]}[mode]
+        bin_names = fam + ["extend_reg_kernel<4> (qlen<=256)", "extend_lds_kernel (longer)"]
         ql = tasks["qlen"].astype(np.int64)
-        which = np.where(ql < 1, 3, np.where(ql <= 64, 0, np.where(ql <= 128, 1, np.where(ql <= 256, 2, 3))))
+        tl = tasks["tlen"].astype(np.int64)
+        which = np.where(ql < 1, 4, np.where(ql <= 32, 0, np.where(ql <= 64, 1, np.where(ql <= 128, 2, np.where(ql <= 256, 3, 4)))))
+        if mode == "grp":
+            which = np.where((ql >= 1) & (ql <= 256) & (tl > 1024), 3, which)
+        if mode == "lds":
+            which[:] = 4
         per_task_bytes = ql + tasks["tlen"].astype(np.int64) + 56  # qlen + tlen + 32 + 24
         kernels = []
-        for b in range(4):
+        for b in range(5):
             nb = int((which == b).sum())
             if nb == 0:
                 continue

@@ -109,12 +109,14 @@ int bmh_ctx_create(bmh_ctx_t **out, int device)
 	    (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess ||
 	    (e = hipEventCreate(&ctx->ev_bin[0])) != hipSuccess || (e = hipEventCreate(&ctx->ev_bin[1])) != hipSuccess ||
 	    (e = hipEventCreate(&ctx->ev_bin[2])) != hipSuccess || (e = hipEventCreate(&ctx->ev_bin[3])) != hipSuccess ||
-	    (e = hipEventCreate(&ctx->ev_bin[4])) != hipSuccess) {
+	    (e = hipEventCreate(&ctx->ev_bin[4])) != hipSuccess || (e = hipEventCreate(&ctx->ev_bin[5])) != hipSuccess) {
 		fprintf(stderr, "[bwamem_hip] context creation failed: %s\n", hipGetErrorString(e));
 		bmh_ctx_destroy(ctx);
 		return BMH_E_NODEVICE;
 	}
 	ctx->stream = ctx->own_stream;
+	if (const char *m = getenv("BMH_EXT_MODE")) ctx->force_kernel = !strcmp(m, "lds") ? 1 : !strcmp(m, "reg") ? 2 : !strcmp(m, "grp") ? 3 : 0;
+	if (const char *m = getenv("BMH_GRID_MULT")) ctx->grid_mult = atoi(m) > 0 ? atoi(m) : 1;
 	*out = ctx;
 	return BMH_OK;
 }
@@ -130,7 +132,7 @@ int bmh_ctx_destroy(bmh_ctx_t *ctx)
 	if (ctx->h_err) (void)hipHostFree(ctx->h_err);
 	if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
 	if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-	for (int b = 0; b < 5; ++b)
+	for (int b = 0; b < 6; ++b)
 		if (ctx->ev_bin[b]) (void)hipEventDestroy(ctx->ev_bin[b]);
 	if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
 	delete ctx;
@@ -199,13 +201,13 @@ int bmh_last_kernel_ms(bmh_ctx_t *ctx, float *ms)
 	return BMH_OK;
 }
 
-int bmh_last_extend_bin_ms(bmh_ctx_t *ctx, float ms[4])
+int bmh_last_extend_bin_ms(bmh_ctx_t *ctx, float ms[5])
 {
 	if (!ctx || !ms) return BMH_E_ARG;
-	for (int b = 0; b < 4; ++b) ms[b] = -1.f;
+	for (int b = 0; b < kExtBins; ++b) ms[b] = -1.f;
 	if (!ctx->ev_bin_valid) return BMH_OK;
-	BMH_HIP(ctx, hipEventSynchronize(ctx->ev_bin[4]));
-	for (int b = 0; b < 4; ++b) BMH_HIP(ctx, hipEventElapsedTime(&ms[b], ctx->ev_bin[b], ctx->ev_bin[b + 1]));
+	BMH_HIP(ctx, hipEventSynchronize(ctx->ev_bin[kExtBins]));
+	for (int b = 0; b < kExtBins; ++b) BMH_HIP(ctx, hipEventElapsedTime(&ms[b], ctx->ev_bin[b], ctx->ev_bin[b + 1]));
 	return BMH_OK;
 }
 

@@ -22,7 +22,8 @@ struct bmh_ctx {
 	// device workspaces of the host-buffer entry points
 	DevBuf d_pool, d_tasks, d_res, d_order, d_cigar, d_scratch;
 	DevBuf d_bins; // per-launch bin lists of the extension dispatcher: 4 counters + 4 x n task indices
-	int force_kernel = 0; // 0 = dispatch by length; 1 = LDS kernel only (debug/A-B, env BMH_FORCE_LDS)
+	int grid_mult = 1;    // env BMH_GRID_MULT: persistent grid = resident waves x this (tuning knob)
+	int force_kernel = 0; // kernels for qlen<=128: 0 lane-per-task, 1 LDS kernel, 2 one task/wave, 3 four tasks/wave (env BMH_EXT_MODE=lds|reg|grp)
 	bool pool_resident = false; // d_pool holds a pool uploaded by bmh_upload_pool()
 	size_t pool_bytes = 0;
 	int *d_err = nullptr; // device error flag (BMH_E_* or 0)
@@ -31,7 +32,7 @@ struct bmh_ctx {
 	bool timing = false;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	bool ev_valid = false;
-	hipEvent_t ev_bin[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // boundaries of the 4 extension bins
+	hipEvent_t ev_bin[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // boundaries of the extension bins
 	bool ev_bin_valid = false;
 	std::string last_error;
 	bmh_driver_stats_t dstats{};
@@ -58,6 +59,12 @@ int launch_extend(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_t
                   bmh_ext_result_t *d_res, const uint32_t *d_order, int qmax);
 int launch_extend_lds(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
                       bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, int qmax);
+constexpr int kExtBins = 5;        // length bins of the extension dispatcher
+constexpr int kGrpTcapHost = 1024; // == kGrpTcap in extend_grp.hip
+int launch_extend_grp(bmh_ctx *ctx, int nv, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
+                      bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count);
+int launch_extend_lane(bmh_ctx *ctx, int c, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
+                       bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count);
 int launch_extend_reg(bmh_ctx *ctx, int ns, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
                       bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count);
 int launch_global(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_glb_task_t *d_tasks, int64_t n,

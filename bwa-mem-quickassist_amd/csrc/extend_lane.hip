@@ -1,0 +1,207 @@
+// extend_lane.hip -- 64 seed extensions per wave64: one LANE per task, DP row state in registers.
+//
+// Same results as ksw_extend2 (reference bwa-0.7.8/ksw.c:379-476) and as the other kernels here.
+//
+// Why (profiles/r01_*): a wave-instruction costs the same 4 cycles whether it advances one
+// task by 64 cells or 64 tasks by one cell each.  With one task per wave (or per 16-lane row) every DP row
+// pays ~60-100 vector instructions of cross-lane scan / reduction / bookkeeping for only ~40 live cells.
+// Here each lane runs the reference's scalar recurrence for ITS OWN task:
+//   * the C = 32/64/128 columns of the row (shifted H and E packed u16|u16 in ONE VGPR per column; the query
+//     as v_perm selectors, 4 per VGPR) live in registers; the column loop is fully unrolled, so all register
+//     indices are static; F and the left neighbour are carried sequentially through the unrolled columns --
+//     no cross-lane operation is left in the kernel;
+//   * the query is RIGHT-ALIGNED in the C columns (column qlen-1 is always position C-1), so the gscore column
+//     is a compile-time position;
+//   * the live interval [beg,end) of a lane is a per-lane bit mask; columns outside it run predicated (their
+//     F / left-neighbour outputs are forced to 0 / first-column value, which is exactly what the first live
+//     column must see, ksw.c:412-416,429); 8-column blocks that no lane of the wave needs are skipped with one
+//     wave-uniform branch;
+//   * the interval update (ksw.c:463-466) needs no second pass: while walking the columns a lane tracks the
+//     last zero seen, the last zero left of the running maximum and the first zero right of it;
+//   * all tasks of a wave start together at row 0, so the row index and the loop are wave-uniform; a lane that
+//     finishes (m==0, z-drop, last row) writes its result and idles until the wave is done.  The dispatcher
+//     hands this kernel tasks SORTED by expected row count, so lanes of a wave finish together.
+#include "bmh_ctx.h"
+#include "bmh_device.h"
+
+namespace bmh {
+
+#ifndef BMH_LANE_HOIST_LIMIT
+#define BMH_LANE_HOIST_LIMIT 128
+#endif
+constexpr int kLaneHoistLimit = BMH_LANE_HOIST_LIMIT;
+// waves per SIMD the register allocator must leave room for (2nd launch-bounds argument)
+#ifndef BMH_LANE_WAVES
+#define BMH_LANE_WAVES(C) ((C) <= 32 ? 4 : (C) <= 64 ? 3 : 2)
+#endif
+
+__device__ __forceinline__ int bfi2(int mask, int a, int b) { return (a & mask) | (b & ~mask); }
+
+template <int C>
+__global__ __launch_bounds__(64, BMH_LANE_WAVES(C)) void extend_lane_kernel(const uint8_t *__restrict__ pool,
+                                                         const bmh_ext_task_t *__restrict__ tasks,
+                                                         const uint32_t *__restrict__ order,
+                                                         const uint32_t *__restrict__ count, long long n,
+                                                         bmh_ext_result_t *__restrict__ out, DevParams P,
+                                                         int *__restrict__ err_flag)
+{
+	constexpr int NW = C / 32, NQ = C / 4, NB = C / 8;
+	constexpr int INF = 0x7fff;
+	__shared__ uint2 srow[8]; // srow[t] = the 5 signed score bytes mat[t*5 .. t*5+4]
+	const int lane = threadIdx.x;
+	const int oe_del = P.o_del + P.e_del, oe_ins = P.o_ins + P.e_ins;
+	const int e_del = P.e_del, e_ins = P.e_ins;
+
+	if (lane < 5) {
+		uint32_t lo = 0;
+		for (int q = 0; q < 4; ++q) lo |= (uint32_t)(uint8_t)mat_at(P, lane * 5 + q) << (8 * q);
+		srow[lane] = make_uint2(lo, (uint32_t)(uint8_t)mat_at(P, lane * 5 + 4));
+	}
+	const long long cnt = count ? (long long)*count : n;
+	const long long base = (long long)blockIdx.x * 64;
+	if (base >= cnt) return;
+	const bool valid = base + lane < cnt;
+	const uint32_t idx = order ? order[valid ? base + lane : base] : (uint32_t)(valid ? base + lane : base);
+
+	const uint4 *tp = (const uint4 *)(tasks + idx);
+	const uint4 ta = tp[0], tb = tp[1];
+	const uint64_t q_off = (uint64_t)ta.y << 32 | ta.x, t_off = (uint64_t)ta.w << 32 | ta.z;
+	const int qlen = (int)(tb.x & 0xffff), tlen = (int)(tb.x >> 16);
+	const int h0 = max((int)tb.y, 0); // ksw.c:384
+	int w = (int)(int16_t)(tb.z & 0xffff);
+	const int end_bonus = (int)(int16_t)(tb.z >> 16);
+	const bool qrev = tb.w & BMH_F_QREV, trev = tb.w & BMH_F_TREV;
+	const bool bad = qlen > C || qlen < 1 || h0 + qlen * P.max_mat > kScoreLimit;
+	if (valid && bad) {
+		int *p = (int *)(out + idx);
+		p[0] = INT32_MIN, p[1] = p[2] = p[3] = p[4] = p[5] = 0;
+		atomicExch(err_flag, BMH_E_RANGE);
+	}
+	const int off = C - min(max(qlen, 1), C);
+
+	// ---- per-lane column state (ksw.c:389-396), query right-aligned
+	int HE[C], QS[NQ];
+#pragma unroll
+	for (int v = 0; v < NQ; ++v) {
+		int s = 0;
+#pragma unroll
+		for (int b = 0; b < 4; ++b) {
+			const int j = 4 * v + b - off;
+			int qb = 4;
+			if (valid && !bad && j >= 0) qb = seq_base(pool, q_off, j, qrev);
+			s |= qb << (8 * b);
+		}
+		QS[v] = s;
+	}
+#pragma unroll
+	for (int p = 0; p < C; ++p) {
+		const int j = p - off;
+		HE[p] = j < 0 ? 0 : (j == 0 ? h0 : max(0, h0 - P.o_ins - j * e_ins));
+	}
+	w = min(w, max(1, band_cap(qlen, P.max_mat, end_bonus, P.o_ins, e_ins))); // ksw.c:398-406
+	w = min(w, max(1, band_cap(qlen, P.max_mat, end_bonus, P.o_del, e_del)));
+
+	int begp = off, endp = C, best = h0, bi = -1, bjp = off - 1, maxoff = 0, raw = h0 - P.o_del, gk = -1;
+	bool alive = valid && !bad && tlen > 0;
+	if (valid && !bad && tlen == 0) { // no rows at all
+		int *p = (int *)(out + idx);
+		p[0] = h0, p[1] = 0, p[2] = 0, p[3] = 0, p[4] = -1, p[5] = 0;
+	}
+	int tnext = alive ? seq_base(pool, t_off, 0, trev) : 0;
+
+	for (int i = 0; __builtin_amdgcn_ballot_w64(alive) != 0; ++i) { // i is wave-uniform: all tasks started together
+		const int tcur = tnext;
+		tnext = 0;
+		if (alive && i + 1 < tlen) tnext = seq_base(pool, t_off, i + 1, trev); // consumed one row later
+		const uint2 row = srow[min(tcur, 4)];
+		begp = max(begp, i - w + off);     // ksw.c:418-420
+		endp = min(endp, i + w + 1 + off); // endp <= C covers the qlen clamp
+		raw -= e_del;
+		const int left = max(raw, 0); // first-column value, ksw.c:415-416
+		const int lb = alive ? begp : C + 1, le = alive ? endp : C + 1;
+		int am[NW];
+#pragma unroll
+		for (int v = 0; v < NW; ++v) {
+			const int lo = min(max(lb - 32 * v, 0), 32), hi = min(max(le - 32 * v, 0), 32);
+			am[v] = hi > lo ? (int)((0xffffffffu >> (32 - (hi - lo))) << lo) : 0;
+		}
+		int f = 0, hprev = left, kmax = -1, hlast = -1;
+		int lz = lb - 2 + (left == 0), lzm = lz, fz = INF;
+#pragma unroll
+		for (int b = 0; b < NB; ++b) {
+			// the block is needed by a lane iff [8b,8b+8) meets [beg,end]  (end itself receives eh[end])
+			if (__builtin_amdgcn_ballot_w64(lb < 8 * b + 8 && le >= 8 * b) == 0) continue;
+#pragma unroll
+			for (int c = 0; c < 8; ++c) {
+				const int p = 8 * b + c;
+				const int actv = (am[p / 32] << (31 - p % 32)) >> 31;
+				// selector = query code of column p in byte 0.  The second operand is never selected; passing a
+				// row-variant value for C >= HOIST_LIMIT keeps hipcc from hoisting C selectors into C more VGPRs.
+				const unsigned sel = __builtin_amdgcn_perm((unsigned)QS[p / 4], C >= kLaneHoistLimit ? row.y : 0u,
+				                                           0x0c0c0c04u + (unsigned)(p % 4));
+				const int sc = (int)(int8_t)__builtin_amdgcn_perm(row.y, row.x, sel);
+				const int e = (int)((unsigned)HE[p] >> 16);
+				const int hh = max((int)(HE[p] & 0xffff) + sc, e);          // ksw.c:430-431
+				const int h = max(hh, f);                                   // ksw.c:432
+				const int en = max(max(e - e_del, h - oe_del), 0) & actv;   // ksw.c:436-439
+				f = max(max(f - e_ins, h - oe_ins), 0) & actv;              // ksw.c:441-444
+				HE[p] = en << 16 | hprev;                                   // eh[j] = {H(i,j-1), E(i+1,j)}, ksw.c:429,440
+				const int ha = bfi2(actv, h, -1);
+				const int key = ha << 16 | p;
+				const bool nm = key > kmax;                                 // ties -> larger j, ksw.c:434
+				kmax = max(kmax, key);
+				lzm = nm ? lz : lzm;
+				fz = nm ? INF : fz;
+				const bool z = ha == 0;
+				lz = z ? p : lz;
+				fz = min(fz, z ? p : INF);
+				hprev = bfi2(actv, h, left);
+				if (p == C - 1) hlast = ha;
+			}
+		}
+		// ---- row end, per lane
+		gk = max(gk, hlast << 16 | i); // column qlen-1 live in this row: ksw.c:447-450 (ties -> later row)
+		if (alive && le <= lb && lb == C) gk = max(gk, left << 16 | i); // empty row whose loop variable equals qlen
+		const int m = kmax < 0 ? 0 : kmax >> 16, mjp = kmax & 0xffff;
+		const bool stop0 = kmax < 0x10000;                                   // m == 0 or empty row, ksw.c:451
+		const bool upd = alive && m > best;                                 // ksw.c:452-454
+		const int dd = (i - bi) - (mjp - bjp);
+		const int pen = max(dd * e_del, -dd * e_ins);
+		const bool zd = !upd && P.zdrop > 0 && best - m - pen > P.zdrop;    // ksw.c:455-461
+		best = upd ? m : best;
+		bi = upd ? i : bi;
+		bjp = upd ? mjp : bjp;
+		maxoff = upd ? max(maxoff, abs(mjp - off - i)) : maxoff;
+		begp = lzm + 2;                                                     // ksw.c:463-464
+		endp = min(fz == INF ? le + 1 : fz + 1, C);                         // ksw.c:465-466
+		const bool done = alive && (stop0 || zd || i + 1 >= tlen);
+		if (done) { // results, ksw.c:470-475
+			alive = false;
+			int *p = (int *)(out + idx);
+			p[0] = best, p[1] = bjp - off + 1, p[2] = bi + 1;
+			p[3] = gk < 0 ? 0 : (gk & 0xffff) + 1, p[4] = gk < 0 ? -1 : gk >> 16, p[5] = maxoff;
+		}
+	}
+}
+
+// ---- launcher: tasks listed in d_order[0..*d_count) must have 1 <= qlen <= C
+int launch_extend_lane(bmh_ctx *ctx, int c, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
+                       bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count)
+{
+	if (n <= 0) return BMH_OK;
+	const long long grid = (n + 63) / 64; // blocks past the bin's device-side count return at once
+#define BMH_LAUNCH_LANE(CC)                                                                                         \
+	hipLaunchKernelGGL(extend_lane_kernel<CC>, dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_pool, d_tasks, d_order, \
+	                   d_count, (long long)n, d_res, ctx->dev, ctx->d_err)
+	switch (c) {
+	case 32: BMH_LAUNCH_LANE(32); break;
+	case 64: BMH_LAUNCH_LANE(64); break;
+	case 128: BMH_LAUNCH_LANE(128); break;
+	default: return BMH_E_ARG;
+	}
+#undef BMH_LAUNCH_LANE
+	BMH_HIP(ctx, hipGetLastError());
+	return BMH_OK;
+}
+
+} // namespace bmh

@@ -153,9 +153,9 @@ int bmh_extend_batch_sharded(bmh_ctx_t *const *ctxs, int n_ctx, const uint8_t *s
  * dominant kernel of the last *_device call.  ms < 0 if none. */
 int bmh_last_kernel_ms(bmh_ctx_t *ctx, float *ms);
 int bmh_set_kernel_timing(bmh_ctx_t *ctx, int enable);
-/* Per-kernel duration of the last extension launch: ms[0..2] = register kernels for qlen<=64 / <=128 /
- * <=256, ms[3] = the LDS kernel (longer queries).  -1 when timing was off. */
-int bmh_last_extend_bin_ms(bmh_ctx_t *ctx, float ms[4]);
+/* Per-kernel duration of the last extension launch, one entry per query-length bin of the dispatcher:
+ * qlen <= 32, <= 64, <= 128, <= 256, longer (LDS kernel).  -1 when timing was off. */
+int bmh_last_extend_bin_ms(bmh_ctx_t *ctx, float ms[5]);
 
 /* ---- L3: data carriers of the extension driver, layout-compatible with the
  * reference so that its structs can be passed straight through. */
