@@ -28,23 +28,43 @@ __device__ __forceinline__ int ext_bin_of(int qlen, int tlen, int mode)
 	return qlen <= 32 ? 0 : qlen <= 64 ? 1 : qlen <= 128 ? 2 : qlen <= 256 ? 3 : 4;
 }
 
-__global__ __launch_bounds__(256) void sort_hist_kernel(const bmh_ext_task_t *__restrict__ tasks,
-                                                        const uint32_t *__restrict__ order, long long n,
-                                                        uint32_t *__restrict__ hist, uint32_t *__restrict__ binkey,
-                                                        int mode)
+// sort key inside a bin: query-length bucket (major; lanes of a wave then share the unused leading columns,
+// which the lane kernels skip) and expected row count (minor; lanes of a wave then finish together).
+// rows run at most to tlen, and the band leaves the query after ~qlen+w <= 2*qlen rows (ksw.c:418).
+__device__ __forceinline__ int ext_sort_key(int bin, int qlen, int tlen)
 {
-	for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long long)gridDim.x * blockDim.x) {
+	if (bin > 2) return 0;
+	const int qlo = bin == 0 ? 1 : (16 << bin) + 1, qsh = bin == 2 ? 2 : 1;
+	const int rows = min(tlen, 2 * qlen + 8);
+	return ((qlen - qlo) >> qsh) * 64 + min(rows >> 3, 63);
+}
+
+constexpr int kSortBlocks = 512, kSortThreads = 256;
+
+// pass 1: per-block histogram in LDS over a contiguous chunk, flushed with one global atomic per used key
+__global__ __launch_bounds__(kSortThreads) void sort_hist_kernel(const bmh_ext_task_t *__restrict__ tasks,
+                                                                 const uint32_t *__restrict__ order, long long n,
+                                                                 uint32_t *__restrict__ hist,
+                                                                 uint16_t *__restrict__ binkey, int mode)
+{
+	__shared__ uint32_t lh[kExtBins * kSortKeys];
+	for (int t = threadIdx.x; t < kExtBins * kSortKeys; t += kSortThreads) lh[t] = 0;
+	__syncthreads();
+	const long long chunk = (n + gridDim.x - 1) / gridDim.x, lo = chunk * blockIdx.x, hi = min(lo + chunk, n);
+	for (long long k = lo + threadIdx.x; k < hi; k += kSortThreads) {
 		const uint32_t idx = order ? order[k] : (uint32_t)k;
 		const int qlen = tasks[idx].qlen, tlen = tasks[idx].tlen;
 		const int bin = ext_bin_of(qlen, tlen, mode);
-		// rows run at most to tlen, and the band leaves the query after ~qlen+w <= 2*qlen rows (ksw.c:418)
-		const int key = bin <= 2 ? min(min(tlen, 2 * qlen + 8), kSortKeys - 1) : 0;
-		binkey[k] = (uint32_t)(bin * kSortKeys + key);
-		atomicAdd(&hist[bin * kSortKeys + key], 1u);
+		const int bk = bin * kSortKeys + ext_sort_key(bin, qlen, tlen);
+		binkey[k] = (uint16_t)bk;
+		atomicAdd(&lh[bk], 1u);
 	}
+	__syncthreads();
+	for (int t = threadIdx.x; t < kExtBins * kSortKeys; t += kSortThreads)
+		if (lh[t]) atomicAdd(&hist[t], lh[t]);
 }
 
-// exclusive scan of each bin's histogram (in place -> scatter offsets) and the bin sizes
+// pass 2: exclusive scan of each bin's histogram (in place -> cursors) and the bin sizes
 __global__ __launch_bounds__(1024) void sort_scan_kernel(uint32_t *__restrict__ hist, uint32_t *__restrict__ counts)
 {
 	__shared__ uint32_t part[1024];
@@ -65,16 +85,26 @@ __global__ __launch_bounds__(1024) void sort_scan_kernel(uint32_t *__restrict__ 
 	}
 }
 
-__global__ __launch_bounds__(256) void sort_scatter_kernel(const uint32_t *__restrict__ order, long long n,
-                                                           uint32_t *__restrict__ offs,
-                                                           const uint32_t *__restrict__ binkey,
-                                                           uint32_t *__restrict__ lists)
+// pass 3: every block re-counts its chunk, reserves one range per used key from the global cursors and
+// places its tasks inside those ranges with LDS atomics
+__global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint32_t *__restrict__ order, long long n,
+                                                                    uint32_t *__restrict__ cursor,
+                                                                    const uint16_t *__restrict__ binkey,
+                                                                    uint32_t *__restrict__ lists)
 {
-	for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long long)gridDim.x * blockDim.x) {
-		const uint32_t idx = order ? order[k] : (uint32_t)k;
+	__shared__ uint32_t lh[kExtBins * kSortKeys];
+	for (int t = threadIdx.x; t < kExtBins * kSortKeys; t += kSortThreads) lh[t] = 0;
+	__syncthreads();
+	const long long chunk = (n + gridDim.x - 1) / gridDim.x, lo = chunk * blockIdx.x, hi = min(lo + chunk, n);
+	for (long long k = lo + threadIdx.x; k < hi; k += kSortThreads) atomicAdd(&lh[binkey[k]], 1u);
+	__syncthreads();
+	for (int t = threadIdx.x; t < kExtBins * kSortKeys; t += kSortThreads)
+		if (lh[t]) lh[t] = atomicAdd(&cursor[t], lh[t]); // count -> start of this block's range
+	__syncthreads();
+	for (long long k = lo + threadIdx.x; k < hi; k += kSortThreads) {
 		const uint32_t bk = binkey[k];
-		const uint32_t pos = atomicAdd(&offs[bk], 1u);
-		lists[(size_t)(bk / kSortKeys) * (size_t)n + pos] = idx;
+		const uint32_t pos = atomicAdd(&lh[bk], 1u);
+		lists[(size_t)(bk / kSortKeys) * (size_t)n + pos] = order ? order[k] : (uint32_t)k;
 	}
 }
 
@@ -86,17 +116,19 @@ int launch_extend(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_t
 	const int mode = ctx->force_kernel; // 0 lane-per-task, 1 lds, 2 reg (1 task/wave), 3 grp (4 tasks/wave)
 	const size_t N = (size_t)n;
 	const size_t hist_words = (size_t)kExtBins * kSortKeys;
-	if ((rc = ensure(ctx, ctx->d_bins, (16 + hist_words + N + (size_t)kExtBins * N) * 4))) return rc;
+	if ((rc = ensure(ctx, ctx->d_bins, (16 + hist_words + (N + 1) / 2 + 1 + (size_t)kExtBins * N) * 4))) return rc;
 	uint32_t *counts = (uint32_t *)ctx->d_bins.p;
-	uint32_t *hist = counts + 16, *binkey = hist + hist_words, *lists = binkey + N;
+	uint32_t *hist = counts + 16;
+	uint16_t *binkey = (uint16_t *)(hist + hist_words);
+	uint32_t *lists = hist + hist_words + (N + 1) / 2 + 1;
 	BMH_HIP(ctx, hipMemsetAsync(counts, 0, (16 + hist_words) * 4, ctx->stream));
-	long long cg = (n + 255) / 256;
-	if (cg > 4096) cg = 4096;
-	hipLaunchKernelGGL(sort_hist_kernel, dim3((unsigned)cg), dim3(256), 0, ctx->stream, d_tasks, d_order, (long long)n, hist,
-	                   binkey, mode);
+	long long cg = (n + 1023) / 1024;
+	if (cg > kSortBlocks) cg = kSortBlocks;
+	hipLaunchKernelGGL(sort_hist_kernel, dim3((unsigned)cg), dim3(kSortThreads), 0, ctx->stream, d_tasks, d_order, (long long)n,
+	                   hist, binkey, mode);
 	hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, hist, counts);
-	hipLaunchKernelGGL(sort_scatter_kernel, dim3((unsigned)cg), dim3(256), 0, ctx->stream, d_order, (long long)n, hist, binkey,
-	                   lists);
+	hipLaunchKernelGGL(sort_scatter_kernel, dim3((unsigned)cg), dim3(kSortThreads), 0, ctx->stream, d_order, (long long)n, hist,
+	                   binkey, lists);
 	BMH_HIP(ctx, hipGetLastError());
 	const bool tm = ctx->timing;
 	if (tm) BMH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));

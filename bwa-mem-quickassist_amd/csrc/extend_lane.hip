@@ -35,7 +35,8 @@ constexpr int kLaneHoistLimit = BMH_LANE_HOIST_LIMIT;
 #define BMH_LANE_WAVES(C) ((C) <= 32 ? 4 : (C) <= 64 ? 3 : 2)
 #endif
 
-__device__ __forceinline__ int bfi2(int mask, int a, int b) { return (a & mask) | (b & ~mask); }
+// per-bit select: mask ? a : b  (one v_bitop3_b32 on gfx950)
+__device__ __forceinline__ int bfi2(int mask, int a, int b) { return __builtin_amdgcn_bitop3_b32(mask, a, b, 0xca); }
 
 template <int C>
 __global__ __launch_bounds__(64, BMH_LANE_WAVES(C)) void extend_lane_kernel(const uint8_t *__restrict__ pool,
@@ -126,7 +127,9 @@ __global__ __launch_bounds__(64, BMH_LANE_WAVES(C)) void extend_lane_kernel(cons
 			am[v] = hi > lo ? (int)((0xffffffffu >> (32 - (hi - lo))) << lo) : 0;
 		}
 		int f = 0, hprev = left, kmax = -1, hlast = -1;
-		int lz = lb - 2 + (left == 0), lzm = lz, fz = INF;
+		int nz[NW]; // bit p set <=> h(i,p) != 0 (junk for columns outside the interval; masked with am[] below)
+#pragma unroll
+		for (int v = 0; v < NW; ++v) nz[v] = 0;
 #pragma unroll
 		for (int b = 0; b < NB; ++b) {
 			// the block is needed by a lane iff [8b,8b+8) meets [beg,end]  (end itself receives eh[end])
@@ -146,15 +149,9 @@ __global__ __launch_bounds__(64, BMH_LANE_WAVES(C)) void extend_lane_kernel(cons
 				const int en = max(max(e - e_del, h - oe_del), 0) & actv;   // ksw.c:436-439
 				f = max(max(f - e_ins, h - oe_ins), 0) & actv;              // ksw.c:441-444
 				HE[p] = en << 16 | hprev;                                   // eh[j] = {H(i,j-1), E(i+1,j)}, ksw.c:429,440
-				const int ha = bfi2(actv, h, -1);
-				const int key = ha << 16 | p;
-				const bool nm = key > kmax;                                 // ties -> larger j, ksw.c:434
-				kmax = max(kmax, key);
-				lzm = nm ? lz : lzm;
-				fz = nm ? INF : fz;
-				const bool z = ha == 0;
-				lz = z ? p : lz;
-				fz = min(fz, z ? p : INF);
+				const int ha = bfi2(actv, h, -1);                           // -1 outside the interval
+				kmax = max(kmax, ha << 16 | p);                             // row max, ties -> larger j (ksw.c:434)
+				nz[p / 32] |= (int)(min((unsigned)h, 1u) << (p % 32)); // only live columns are looked at later (& am)
 				hprev = bfi2(actv, h, left);
 				if (p == C - 1) hlast = ha;
 			}
@@ -172,8 +169,26 @@ __global__ __launch_bounds__(64, BMH_LANE_WAVES(C)) void extend_lane_kernel(cons
 		bi = upd ? i : bi;
 		bjp = upd ? mjp : bjp;
 		maxoff = upd ? max(maxoff, abs(mjp - off - i)) : maxoff;
-		begp = lzm + 2;                                                     // ksw.c:463-464
-		endp = min(fz == INF ? le + 1 : fz + 1, C);                         // ksw.c:465-466
+		// live-interval update, ksw.c:463-466, from the zero map of the live columns:
+		//   eh[j].h == 0 for beg < j <= mj  <=>  h(i,j-1) == 0  -> last zero column left of mj, else eh[beg].h = first-column value
+		//   eh[j].h == 0 for mj+2 <= j <= end <=> h(i,j-1) == 0  -> first zero column right of mj, else end+1
+		int lzm = lb - 2 + (left == 0), fz = INF;
+#pragma unroll
+		for (int v = 0; v < NW; ++v) {
+			const int zz = ~nz[v] & am[v];
+			const int lim = mjp - 32 * v; // columns < mj
+			const int zl = lim <= 0 ? 0 : (lim >= 32 ? zz : zz & ((1 << lim) - 1));
+			if (zl) lzm = 32 * v + 31 - __builtin_clz(zl);
+		}
+#pragma unroll
+		for (int v = NW - 1; v >= 0; --v) {
+			const int zz = ~nz[v] & am[v];
+			const int lo = mjp + 1 - 32 * v; // columns > mj
+			const int zr = lo >= 32 ? 0 : (lo <= 0 ? zz : zz & (-1 << lo));
+			if (zr) fz = 32 * v + __builtin_ctz(zr);
+		}
+		begp = lzm + 2;
+		endp = min(fz == INF ? le + 1 : fz + 1, C);
 		const bool done = alive && (stop0 || zd || i + 1 >= tlen);
 		if (done) { // results, ksw.c:470-475
 			alive = false;
