@@ -18,7 +18,7 @@ namespace bmh {
 
 // Counting sort of the tasks by (bin, expected row count): three tiny kernels, no host round trip.
 // The lane-per-task kernels want neighbouring tasks to run for a similar number of rows.
-constexpr int kSortKeys = 1024;
+constexpr int kSortKeys = 2048;
 
 __device__ __forceinline__ int ext_bin_of(int qlen, int tlen, int mode)
 {
@@ -29,14 +29,16 @@ __device__ __forceinline__ int ext_bin_of(int qlen, int tlen, int mode)
 }
 
 // sort key inside a bin: query-length bucket (major; lanes of a wave then share the unused leading columns,
-// which the lane kernels skip) and expected row count (minor; lanes of a wave then finish together).
+// which the lane kernels skip), h0 bucket, and expected row count (minor; lanes of a wave then finish together).
 // rows run at most to tlen, and the band leaves the query after ~qlen+w <= 2*qlen rows (ksw.c:418).
-__device__ __forceinline__ int ext_sort_key(int bin, int qlen, int tlen)
+__device__ __forceinline__ int ext_sort_key(int bin, int qlen, int tlen, int h0)
 {
 	if (bin > 2) return 0;
-	const int qlo = bin == 0 ? 1 : (16 << bin) + 1, qsh = bin == 2 ? 2 : 1;
+	const int qlo = bin == 0 ? 1 : (16 << bin) + 1, qsh = bin == 2 ? 2 : 1; // 16 query-length buckets per bin
 	const int rows = min(tlen, 2 * qlen + 8);
-	return ((qlen - qlo) >> qsh) * 64 + min(rows >> 3, 63);
+	// h0 decides how wide the live interval is (cells stay non-zero within ~h0-o-e of the diagonal), so lanes
+	// with a similar h0 need the same 8-column blocks
+	return (((qlen - qlo) >> qsh) * 8 + min(max(h0, 0) >> 4, 7)) * 16 + min(rows >> 4, 15);
 }
 
 constexpr int kSortBlocks = 512, kSortThreads = 256;
@@ -55,7 +57,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_hist_kernel(const bmh_ext_t
 		const uint32_t idx = order ? order[k] : (uint32_t)k;
 		const int qlen = tasks[idx].qlen, tlen = tasks[idx].tlen;
 		const int bin = ext_bin_of(qlen, tlen, mode);
-		const int bk = bin * kSortKeys + ext_sort_key(bin, qlen, tlen);
+		const int bk = bin * kSortKeys + ext_sort_key(bin, qlen, tlen, tasks[idx].h0);
 		binkey[k] = (uint16_t)bk;
 		atomicAdd(&lh[bk], 1u);
 	}
@@ -67,19 +69,22 @@ __global__ __launch_bounds__(kSortThreads) void sort_hist_kernel(const bmh_ext_t
 // pass 2: exclusive scan of each bin's histogram (in place -> cursors) and the bin sizes
 __global__ __launch_bounds__(1024) void sort_scan_kernel(uint32_t *__restrict__ hist, uint32_t *__restrict__ counts)
 {
+	static_assert(kSortKeys == 2048, "two keys per thread");
 	__shared__ uint32_t part[1024];
 	const int t = threadIdx.x;
 	for (int b = 0; b < kExtBins; ++b) {
-		const uint32_t v = hist[b * kSortKeys + t];
-		part[t] = v;
+		const uint32_t v0 = hist[b * kSortKeys + 2 * t], v1 = hist[b * kSortKeys + 2 * t + 1];
+		part[t] = v0 + v1;
 		__syncthreads();
-		for (int d = 1; d < 1024; d <<= 1) { // Hillis-Steele inclusive scan, 1024 threads
+		for (int d = 1; d < 1024; d <<= 1) { // Hillis-Steele inclusive scan over the pair sums
 			const uint32_t add = t >= d ? part[t - d] : 0;
 			__syncthreads();
 			part[t] += add;
 			__syncthreads();
 		}
-		hist[b * kSortKeys + t] = part[t] - v;
+		const uint32_t excl = part[t] - (v0 + v1);
+		hist[b * kSortKeys + 2 * t] = excl;
+		hist[b * kSortKeys + 2 * t + 1] = excl + v0;
 		if (t == 1023) counts[b] = part[t];
 		__syncthreads();
 	}

@@ -62,7 +62,10 @@ __global__ __launch_bounds__(64, BMH_LANE_WAVES(C)) void extend_lane_kernel(cons
 	const long long base = (long long)blockIdx.x * 64;
 	if (base >= cnt) return;
 	const bool valid = base + lane < cnt;
-	const uint32_t idx = order ? order[valid ? base + lane : base] : (uint32_t)(valid ? base + lane : base);
+	// the bin list is sorted ascending (short queries / few rows first); walk it from the back so the most
+	// expensive waves are dispatched first and the cheap ones fill the tail
+	const long long pos = cnt - 1 - (valid ? base + lane : base);
+	const uint32_t idx = order ? order[pos] : (uint32_t)pos;
 
 	const uint4 *tp = (const uint4 *)(tasks + idx);
 	const uint4 ta = tp[0], tb = tp[1];
