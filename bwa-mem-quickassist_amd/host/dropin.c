@@ -10,12 +10,32 @@
  * Failure convention = the reference's: there is no error return on
  * this path, so any library error aborts loudly; nothing falls back to the CPU.
  */
+#define _GNU_SOURCE
+#include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include "../../include/bwamem_hip.h"
 #include "tls_ctx.h"
+
+/* BMH_KSW_DROPIN=0 in the environment leaves ksw_extend2/ksw_global2 to the NEXT definition in link
+ * order (the host program's own CPU code) -- used to time "batched phase 1 on the GPU, phase 2 untouched"
+ * (tools/pipeline_bench.py).  This is a routing switch of the preload shim, not a fallback: the library's
+ * own entry points never run DP on the CPU. */
+static int ksw_dropin_enabled(void)
+{
+	static int v = -1;
+	if (v < 0) {
+		const char *e = getenv("BMH_KSW_DROPIN");
+		v = !(e && e[0] == '0');
+	}
+	return v;
+}
+typedef int (*ext2_fn)(int, const uint8_t *, int, const uint8_t *, int, const int8_t *, int, int, int, int, int, int, int, int,
+                       int *, int *, int *, int *, int *);
+typedef int (*glb2_fn)(int, const uint8_t *, int, const uint8_t *, int, const int8_t *, int, int, int, int, int, int *,
+                       uint32_t **);
 
 int ksw_extend2(int qlen, const uint8_t *query, int tlen, const uint8_t *target, int m, const int8_t *mat, int o_del,
                 int e_del, int o_ins, int e_ins, int w, int end_bonus, int zdrop, int h0, int *qle, int *tle, int *gtle,
@@ -27,6 +47,13 @@ int ksw_extend2(int qlen, const uint8_t *query, int tlen, const uint8_t *target,
 	uint8_t *pool;
 	bmh_ctx_t *ctx;
 	int rc;
+	if (!ksw_dropin_enabled()) {
+		static ext2_fn next;
+		if (!next) next = (ext2_fn)dlsym(RTLD_NEXT, "ksw_extend2");
+		if (!next) bmh_tls_die("BMH_KSW_DROPIN=0 but no other ksw_extend2 is loaded", BMH_E_ARG);
+		return next(qlen, query, tlen, target, m, mat, o_del, e_del, o_ins, e_ins, w, end_bonus, zdrop, h0, qle, tle, gtle, gscore,
+		            max_off);
+	}
 	if (m != 5) bmh_tls_die("ksw_extend2 drop-in supports m == 5 only", BMH_E_RANGE);
 	memset(&p, 0, sizeof(p));
 	p.o_del = o_del, p.e_del = e_del, p.o_ins = o_ins, p.e_ins = e_ins, p.zdrop = zdrop;
@@ -60,6 +87,12 @@ int ksw_global2(int qlen, const uint8_t *query, int tlen, const uint8_t *target,
 	uint32_t *cig = 0;
 	bmh_ctx_t *ctx;
 	int rc, want = n_cigar_ && cigar_; /* ksw.c:566 */
+	if (!ksw_dropin_enabled()) {
+		static glb2_fn next;
+		if (!next) next = (glb2_fn)dlsym(RTLD_NEXT, "ksw_global2");
+		if (!next) bmh_tls_die("BMH_KSW_DROPIN=0 but no other ksw_global2 is loaded", BMH_E_ARG);
+		return next(qlen, query, tlen, target, m, mat, o_del, e_del, o_ins, e_ins, w, n_cigar_, cigar_);
+	}
 	if (m != 5) bmh_tls_die("ksw_global2 drop-in supports m == 5 only", BMH_E_RANGE);
 	if (n_cigar_) *n_cigar_ = 0; /* ksw.c:507 */
 	memset(&p, 0, sizeof(p));

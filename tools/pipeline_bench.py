@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Whole-pipeline DUT/REF timing on the GPU box (informational; bench.py is the contract metric).
+
+REF = the reference `bwa mem` compiled by oracle/Makefile; DUT = the same binary with
+libbwamem_hip_dropin.so preloaded (phase 1 through bmh_chain2aln_batch, ksw_global2 per-call on the GPU).
+Reads/s are taken from the reference's own per-chunk line
+  [M::mem_process_seqs] Processed N reads in X CPU sec, Y real sec      (reference bwamem.c:1320-1321)
+which excludes index loading.  SAM equality is checked as well.
+Usage: python tools/pipeline_bench.py [--reads 200000] [--genome 4600000] [--threads 16,64]
+"""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import kswgen  # noqa: E402
+import reflib  # noqa: E402
+from __graft_entry__ import load_package  # noqa: E402
+
+
+def sim_reads_fast(rng, ref, n, L):
+    """Vectorised read simulator: 2 % substitutions, 0.25 % 1-bp deletions, 0.25 % 1-bp insertions, 50 % revcomp."""
+    M = 24  # spare bases so that deletions never leave the read short
+    pos = rng.integers(0, len(ref) - L - M - 8, size=n)
+    idx = pos[:, None] + np.arange(L + M)[None, :]
+    frag = ref[idx]
+    out = np.empty((n, L), dtype=np.uint8)
+    for k in range(n):
+        f = frag[k]
+        u = rng.random(L + M)
+        keep = u >= 0.0025                      # deletions
+        f = f[keep]
+        ins = np.nonzero(rng.random(len(f)) < 0.0025)[0]
+        if len(ins):
+            f = np.insert(f, ins, rng.integers(0, 4, size=len(ins)))
+        f = f[:L].copy()
+        sub = rng.random(L) < 0.02
+        f[sub] = (f[sub] + rng.integers(1, 4, size=int(sub.sum()))) & 3
+        if rng.random() < 0.5:
+            f = (3 - f[::-1])
+        out[k] = f
+    return out
+
+
+def run(fa, fq, threads, batch, preload, out, ksw_dropin=True):
+    env = dict(os.environ)
+    if preload:
+        env["LD_PRELOAD"] = load_package().DROPIN_PATH
+        env["BMH_KSW_DROPIN"] = "1" if ksw_dropin else "0"
+    t0 = time.time()
+    with open(out, "w") as f:
+        p = subprocess.run([reflib.REF_BWA, "mem", "-t", str(threads), "-b", str(batch), fa, fq], stdout=f,
+                           stderr=subprocess.PIPE, env=env, check=True, timeout=3000)
+    wall = time.time() - t0
+    reads = real = 0
+    for m in re.finditer(r"Processed (\d+) reads in ([\d.]+) CPU sec, ([\d.]+) real sec", p.stderr.decode()):
+        reads += int(m.group(1))
+        real += float(m.group(3))
+    return {"reads": reads, "process_seqs_real_s": real, "reads_per_s": reads / real if real else None, "wall_s": wall}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reads", type=int, default=200000)
+    ap.add_argument("--genome", type=int, default=4600000)
+    ap.add_argument("--threads", default="16,64")
+    ap.add_argument("--batch", type=int, default=8192)
+    ap.add_argument("--full", action="store_true", help="also time the per-call ksw_global2 GPU drop-in (slow by design)")
+    a = ap.parse_args()
+    rng = np.random.default_rng(20261007)
+    tmp = tempfile.mkdtemp(prefix="bmh_pipe_")
+    ref = kswgen.rand_seq(rng, a.genome)
+    fa, fq = os.path.join(tmp, "ref.fa"), os.path.join(tmp, "reads.fq")
+    reflib.write_fasta(fa, "synth", ref)
+    t0 = time.time()
+    reflib.build_index(fa)
+    t_index = time.time() - t0
+    reads = sim_reads_fast(rng, ref, a.reads, 150)
+    reflib.write_fastq(fq, list(reads))
+    res = {"genome_bp": a.genome, "reads": a.reads, "index_s": t_index, "runs": []}
+    for t in [int(x) for x in a.threads.split(",")]:
+        r = run(fa, fq, t, a.batch, False, os.path.join(tmp, "ref.sam"))
+        refsam = [l for l in open(os.path.join(tmp, "ref.sam")) if not l.startswith("@PG")]
+        d1 = run(fa, fq, t, a.batch, True, os.path.join(tmp, "dut.sam"), ksw_dropin=False)
+        same1 = refsam == [l for l in open(os.path.join(tmp, "dut.sam")) if not l.startswith("@PG")]
+        d2 = None
+        if a.full:
+            d2 = run(fa, fq, t, a.batch, True, os.path.join(tmp, "dut.sam"), ksw_dropin=True)
+            d2["sam_identical"] = refsam == [l for l in open(os.path.join(tmp, "dut.sam")) if not l.startswith("@PG")]
+        res["runs"].append({"threads": t, "batch": a.batch, "ref": r, "dut_phase1_gpu": d1, "sam_identical": same1,
+                            "dut_phase1_gpu_plus_percall_global": d2})
+        print(json.dumps(res["runs"][-1]), flush=True)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
