@@ -36,6 +36,10 @@ PARAMS = np.dtype([("o_del", "<i4"), ("e_del", "<i4"), ("o_ins", "<i4"), ("e_ins
                    ("zdrop", "<i4"), ("a", "<i4"), ("w", "<i4"), ("pen_clip5", "<i4"),
                    ("pen_clip3", "<i4"), ("mat", "i1", (25,)), ("pad", "i1", (3,))])
 SEED = np.dtype([("rbeg", "<i8"), ("qbeg", "<i4"), ("len", "<i4")])
+CIGAR_REQ = np.dtype([("read", "<i4"), ("qb", "<i4"), ("qe", "<i4"), ("pad", "<i4"), ("rb", "<i8"), ("re", "<i8"),
+                      ("truesc", "<i4"), ("reg_w", "<i4")])
+CIGAR_RES = np.dtype([("score", "<i4"), ("n_cigar", "<i4"), ("NM", "<i4"), ("tries", "<i4"), ("cigar_off", "<u4"),
+                      ("md_off", "<u4"), ("md_len", "<u4"), ("rsv", "<u4")])
 ALNREG = np.dtype([("rb", "<i8"), ("re", "<i8"), ("qb", "<i4"), ("qe", "<i4"), ("score", "<i4"),
                    ("truesc", "<i4"), ("sub", "<i4"), ("csub", "<i4"), ("sub_n", "<i4"),
                    ("w", "<i4"), ("seedcov", "<i4"), ("secondary", "<i4"), ("hash", "<u8")])
@@ -101,6 +105,8 @@ def lib():
         L.bmh_chain2aln_batch.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p]
         L.bmh_driver_stats.argtypes = [C.c_void_p, C.c_void_p]
+        L.bmh_reg2cigar_batch.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
         _lib = L
     return _lib
 
@@ -231,6 +237,27 @@ class Context:
             out.append(a)
         self._check(rc)
         return out
+
+    def reg2cigar_batch(self, l_pac, pac, reads, reqs):
+        """Batched mem_reg2aln band/retry loop over bwa_gen_cigar2 (reference bwamem.c:1187-1201, bwa.c:89-172).
+        reads: list of uint8 code arrays; reqs: CIGAR_REQ array.  Returns (results, cigar_pool, md_bytes)."""
+        pac = np.ascontiguousarray(pac, dtype=np.uint8)
+        reqs = np.ascontiguousarray(reqs, dtype=CIGAR_REQ)
+        keep = []
+        c_reads = (_Read * max(len(reads), 1))()
+        for r, seq in enumerate(reads):
+            seq = np.ascontiguousarray(seq, dtype=np.uint8)
+            keep.append(seq)
+            c_reads[r].l_seq, c_reads[r].seq = len(seq), seq.ctypes.data
+        span = (reqs["qe"] - reqs["qb"]).astype(np.int64) + (reqs["re"] - reqs["rb"]).astype(np.int64)
+        span = np.maximum(span, 0)
+        cw, mb = int(span.sum() + 2 * len(reqs) + 8), int(3 * span.sum() + 16 * len(reqs) + 16)
+        res = np.zeros(len(reqs), dtype=CIGAR_RES)
+        cig = np.zeros(cw, dtype=np.uint32)
+        md = np.zeros(mb, dtype=np.uint8)
+        self._check(lib().bmh_reg2cigar_batch(self._h, int(l_pac), _ptr(pac), C.cast(c_reads, C.c_void_p), len(reqs),
+                                              _ptr(reqs), _ptr(res), _ptr(cig), cw, _ptr(md), mb))
+        return res, cig, md
 
     def driver_stats(self):
         st = _DriverStats()

@@ -373,10 +373,15 @@ int bmh_global_batch_device(bmh_ctx_t *ctx, const uint8_t *d_pool, const bmh_glb
 int bmh_global_batch(bmh_ctx_t *ctx, const uint8_t *pool, size_t pool_bytes, const bmh_glb_task_t *tasks, int64_t n,
                      bmh_glb_result_t *results, uint32_t *cigar_pool, size_t cigar_words)
 {
-	if (!ctx || n < 0 || (n > 0 && (!pool || !tasks || !results))) return BMH_E_ARG;
+	if (!ctx || n < 0 || (n > 0 && (!tasks || !results))) return BMH_E_ARG;
 	if (!ctx->have_params) return BMH_E_ARG;
 	if (n == 0) return BMH_OK;
 	if (n > 0xffffffffLL) return BMH_E_ARG;
+	const bool resident = pool == nullptr; // use the pool left on the device by bmh_upload_pool()
+	if (resident) {
+		if (!ctx->pool_resident) return BMH_E_ARG;
+		pool_bytes = ctx->pool_bytes;
+	}
 	int qmax = 1, tmax = 1, wmax = 0, rc;
 	for (int64_t k = 0; k < n; ++k) {
 		const bmh_glb_task_t &x = tasks[k];
@@ -392,12 +397,15 @@ int bmh_global_batch(bmh_ctx_t *ctx, const uint8_t *pool, size_t pool_bytes, con
 	std::vector<uint32_t> ord((size_t)n);
 	std::iota(ord.begin(), ord.end(), 0u);
 	std::stable_sort(ord.begin(), ord.end(), [tasks](uint32_t a, uint32_t b) { return tasks[a].tlen > tasks[b].tlen; });
-	if ((rc = ensure(ctx, ctx->d_pool, pool_bytes + 16))) return rc;
+	if (!resident) {
+		ctx->pool_resident = false;
+		if ((rc = ensure(ctx, ctx->d_pool, pool_bytes + 16))) return rc;
+	}
 	if ((rc = ensure(ctx, ctx->d_tasks, (size_t)n * sizeof(bmh_glb_task_t)))) return rc;
 	if ((rc = ensure(ctx, ctx->d_res, (size_t)n * sizeof(bmh_glb_result_t)))) return rc;
 	if ((rc = ensure(ctx, ctx->d_order, (size_t)n * 4))) return rc;
 	if ((rc = ensure(ctx, ctx->d_cigar, (cigar_words + 4) * 4))) return rc;
-	BMH_HIP(ctx, hipMemcpyAsync(ctx->d_pool.p, pool, pool_bytes, hipMemcpyHostToDevice, ctx->stream));
+	if (!resident) BMH_HIP(ctx, hipMemcpyAsync(ctx->d_pool.p, pool, pool_bytes, hipMemcpyHostToDevice, ctx->stream));
 	BMH_HIP(ctx, hipMemcpyAsync(ctx->d_tasks.p, tasks, (size_t)n * sizeof(bmh_glb_task_t), hipMemcpyHostToDevice, ctx->stream));
 	BMH_HIP(ctx, hipMemcpyAsync(ctx->d_order.p, ord.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
 	if ((rc = launch_global(ctx, (const uint8_t *)ctx->d_pool.p, (const bmh_glb_task_t *)ctx->d_tasks.p, n,

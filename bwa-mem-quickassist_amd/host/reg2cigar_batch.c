@@ -1,0 +1,223 @@
+/*
+ * reg2cigar_batch.c -- batched CIGAR generation: the caller of ksw_global2 on BWA-MEM's path
+ * (SURVEY.md §8 row a6), host side, plain C, above the C-ABI.
+ *
+ * For a batch of alignment regions it does what mem_reg2aln() does per region between
+ * bwa_fix_xref2 and the clipping (reference bwa-0.7.8/bwamem.c:1187-1201):
+ *     w2 = max(infer_bw(del), infer_bw(ins)) capped by the region's band     bwamem.c:884-891,1187-1191
+ *     up to 3 x { bwa_gen_cigar2(w2); stop if the score repeats; w2 <<= 1 }
+ *                 while score < truesc - a                                    bwamem.c:1193-1201
+ * and inside each try what bwa_gen_cigar2() does (bwa.c:89-172): fetch [rb,re) from the 2-bit
+ * reference, reverse query and reference when the hit is on the reverse strand (so indels are
+ * left-aligned), pick the band (bwa.c:116-125), run the banded global alignment, derive NM and MD.
+ * The global alignments of all regions still in play form ONE bmh_global_batch() per try ("round"),
+ * at most three rounds per batch; band choice, the no-gap shortcut (bwa.c:108-114), NM and MD are host
+ * work.  Results are bit-identical to the per-region reference calls.
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/bwamem_hip.h"
+
+const bmh_params_t *bmh_ctx_params_(const bmh_ctx_t *ctx);
+int bmh_upload_pool(bmh_ctx_t *ctx, const uint8_t *pool, size_t bytes);
+
+static void put_num(char *s, size_t *l, int c) /* kputw, kstring.h:62-77, c >= 0 */
+{
+	char buf[16];
+	int n = 0;
+	if (c == 0) { s[(*l)++] = '0'; return; }
+	for (; c > 0; c /= 10) buf[n++] = (char)('0' + c % 10);
+	while (n) s[(*l)++] = buf[--n];
+}
+
+/* bwa.c:134-164; md must have room for 3*(ql+tl)+16 bytes.  Returns NM, *md_len without the NUL. */
+static int nm_md(int n_cigar, const uint32_t *cigar, const uint8_t *q, const uint8_t *t, int rev, char *md, size_t *md_len)
+{
+	const char *int2base = rev ? "TGCAN" : "ACGTN";
+	int k, i, x = 0, y = 0, u = 0, n_mm = 0, n_gap = 0;
+	size_t l = 0;
+	for (k = 0; k < n_cigar; ++k) {
+		const int op = (int)(cigar[k] & 0xf), len = (int)(cigar[k] >> 4);
+		if (op == 0) {
+			for (i = 0; i < len; ++i) {
+				if (q[x + i] != t[y + i]) {
+					put_num(md, &l, u);
+					md[l++] = int2base[t[y + i]];
+					++n_mm, u = 0;
+				} else ++u;
+			}
+			x += len, y += len;
+		} else if (op == 2) {
+			if (k > 0 && k < n_cigar - 1) {
+				put_num(md, &l, u);
+				md[l++] = '^';
+				for (i = 0; i < len; ++i) md[l++] = int2base[t[y + i]];
+				u = 0, n_gap += len;
+			}
+			y += len;
+		} else if (op == 1) x += len, n_gap += len;
+	}
+	put_num(md, &l, u);
+	md[l] = 0;
+	*md_len = l;
+	return n_mm + n_gap;
+}
+
+static int infer_bw(int l1, int l2, int score, int a, int q, int r) /* bwamem.c:884-891 */
+{
+	int w;
+	if (l1 == l2 && l1 * a - score < (q + r - a) << 1) return 0;
+	w = (int)((double)((l1 < l2 ? l1 : l2) * a - score - q) / r + 2.);
+	if (w < abs(l1 - l2)) w = abs(l1 - l2);
+	return w;
+}
+
+typedef struct {
+	uint64_t q_off, t_off; /* oriented copies in the pool */
+	int ql, tl, w2, last_sc, tries, active, rev, valid, nodp;
+	int score, n_cigar;
+	uint32_t slot;  /* cigar scratch slot of the current round */
+	uint32_t fslot; /* this region's fixed slot in the keeper array */
+} cg_t;
+
+int bmh_reg2cigar_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, const bmh_read_t *reads, int64_t n_req,
+                        const bmh_cigar_req_t *reqs, bmh_cigar_res_t *res, uint32_t *cigar_pool, size_t cigar_words,
+                        char *md_pool, size_t md_bytes)
+{
+	const bmh_params_t *p;
+	cg_t *cg = 0;
+	uint8_t *pool = 0;
+	bmh_glb_task_t *tasks = 0;
+	bmh_glb_result_t *gres = 0;
+	uint32_t *scratch = 0, *final_cig = 0;
+	int64_t *owner = 0, k, n_active;
+	size_t pool_bytes = 0, scratch_words = 0, cig_used = 0, md_used = 0;
+	int rc = BMH_OK, round;
+
+	if (!ctx || n_req < 0 || (n_req > 0 && (!reads || !reqs || !res || !pac))) return BMH_E_ARG;
+	p = bmh_ctx_params_(ctx);
+	if (!p) return BMH_E_ARG;
+	if (n_req == 0) return BMH_OK;
+
+	cg = (cg_t *)calloc((size_t)n_req, sizeof(cg_t));
+	if (!cg) return BMH_E_NOMEM;
+	for (k = 0; k < n_req; ++k) { /* layout of the oriented sequence copies */
+		const bmh_cigar_req_t *r = &reqs[k];
+		cg_t *c = &cg[k];
+		const int ql = r->qe - r->qb;
+		const int64_t tl = r->re - r->rb;
+		memset(&res[k], 0, sizeof(res[k]));
+		res[k].NM = -1;
+		c->valid = !(ql <= 0 || r->rb >= r->re || (r->rb < l_pac && r->re > l_pac) || r->rb < 0 || r->re > l_pac << 1); /* bwa.c:99-101 */
+		if (!c->valid) continue;
+		if (ql > 65535 || tl > 65535) { rc = BMH_E_RANGE; goto done; }
+		c->ql = ql, c->tl = (int)tl, c->rev = r->rb >= l_pac;
+		c->q_off = pool_bytes, pool_bytes += (size_t)ql;
+		c->t_off = pool_bytes, pool_bytes += (size_t)tl;
+		c->fslot = (uint32_t)scratch_words;
+		scratch_words += (size_t)ql + (size_t)tl + 2;
+	}
+	pool = (uint8_t *)malloc(pool_bytes + 16);
+	tasks = (bmh_glb_task_t *)malloc(sizeof(*tasks) * (size_t)n_req);
+	gres = (bmh_glb_result_t *)malloc(sizeof(*gres) * (size_t)n_req);
+	owner = (int64_t *)malloc(sizeof(int64_t) * (size_t)n_req);
+	scratch = (uint32_t *)malloc(4 * (scratch_words + 4));
+	final_cig = (uint32_t *)malloc(4 * (scratch_words + 4)); /* last try's CIGAR of every region, same slots */
+	if (!pool || !tasks || !gres || !owner || !scratch || !final_cig) { rc = BMH_E_NOMEM; goto done; }
+
+	for (k = 0; k < n_req; ++k) { /* oriented copies (bwa.c:100-107) and the initial band (bwamem.c:1187-1191) */
+		const bmh_cigar_req_t *r = &reqs[k];
+		cg_t *c = &cg[k];
+		const uint8_t *rq;
+		uint8_t *q, *t;
+		int i, tmp;
+		if (!c->valid) continue;
+		rq = reads[r->read].seq + r->qb, q = pool + c->q_off, t = pool + c->t_off;
+		if (!c->rev) {
+			int64_t x;
+			memcpy(q, rq, (size_t)c->ql);
+			for (x = r->rb, i = 0; x < r->re; ++x, ++i) t[i] = (uint8_t)(pac[x >> 2] >> ((~x & 3) << 1) & 3);
+		} else { /* reverse-strand window = complement read backwards (bntseq.c:364-368), then reversed again (bwa.c:105) */
+			const int64_t lo = (l_pac << 1) - 1 - r->re; /* forward coordinates (lo, hi] */
+			int64_t x;
+			for (i = 0; i < c->ql; ++i) q[i] = rq[c->ql - 1 - i];
+			for (x = lo + 1, i = 0; i < c->tl; ++x, ++i) t[i] = (uint8_t)(3 - (pac[x >> 2] >> ((~x & 3) << 1) & 3));
+		}
+		tmp = infer_bw(c->ql, c->tl, r->truesc, p->a, p->o_del, p->e_del);
+		c->w2 = infer_bw(c->ql, c->tl, r->truesc, p->a, p->o_ins, p->e_ins);
+		c->w2 = c->w2 > tmp ? c->w2 : tmp;
+		if (c->w2 > p->w) c->w2 = c->w2 < r->reg_w ? c->w2 : r->reg_w;
+		c->last_sc = -(1 << 30), c->active = 1;
+	}
+	memset(pool + pool_bytes, 0, 16);
+
+	for (round = 0; round < 3; ++round) { /* bwamem.c:1194-1201, all regions in lock step */
+		size_t slot = 0;
+		n_active = 0;
+		for (k = 0; k < n_req; ++k) {
+			cg_t *c = &cg[k];
+			if (!c->active) continue;
+			++c->tries;
+			c->slot = (uint32_t)slot, c->nodp = 0;
+			if (c->ql == c->tl && c->w2 == 0) { /* no gap, no DP: bwa.c:108-114 */
+				const uint8_t *q = pool + c->q_off, *t = pool + c->t_off;
+				int i, sc = 0;
+				for (i = 0; i < c->ql; ++i) sc += p->mat[t[i] * 5 + q[i]];
+				final_cig[c->fslot] = (uint32_t)c->ql << 4; /* straight into the keeper: the GPU call rewrites `scratch` */
+				c->score = sc, c->n_cigar = 1, c->nodp = 1;
+				slot += 1;
+			} else { /* band of this try, bwa.c:116-125 */
+				bmh_glb_task_t *t = &tasks[n_active];
+				const int max_ins = (int)((double)(((c->ql + 1) >> 1) * p->mat[0] - p->o_ins) / p->e_ins + 1.);
+				const int max_del = (int)((double)(((c->ql + 1) >> 1) * p->mat[0] - p->o_del) / p->e_del + 1.);
+				int max_gap = max_ins > max_del ? max_ins : max_del, w, min_w;
+				max_gap = max_gap > 1 ? max_gap : 1;
+				w = (max_gap + abs(c->tl - c->ql) + 1) >> 1;
+				w = w < c->w2 ? w : c->w2;
+				min_w = abs(c->tl - c->ql) + 3;
+				w = w > min_w ? w : min_w;
+				t->q_off = c->q_off, t->t_off = c->t_off, t->qlen = (uint16_t)c->ql, t->tlen = (uint16_t)c->tl, t->w = w;
+				t->cigar_off = (uint32_t)slot, t->cigar_cap = (uint32_t)(c->ql + c->tl + 2);
+				slot += t->cigar_cap;
+				owner[n_active++] = k;
+			}
+		}
+		if (n_active > 0) {
+			if (round == 0) { if ((rc = bmh_upload_pool(ctx, pool, pool_bytes + 16))) goto done; }
+			if ((rc = bmh_global_batch(ctx, 0, 0, tasks, n_active, gres, scratch, scratch_words + 4))) goto done;
+			for (k = 0; k < n_active; ++k) cg[owner[k]].score = gres[k].score, cg[owner[k]].n_cigar = gres[k].n_cigar;
+		}
+		n_active = 0;
+		for (k = 0; k < n_req; ++k) { /* keep this try's CIGAR, decide about the next one */
+			cg_t *c = &cg[k];
+			if (!c->active) continue;
+			if (!c->nodp) memcpy(final_cig + c->fslot, scratch + c->slot, 4 * (size_t)c->n_cigar);
+			if (c->score == c->last_sc) c->active = 0; /* bwamem.c:1198 */
+			else {
+				c->last_sc = c->score, c->w2 <<= 1;
+				if (!(c->tries < 3 && c->score < reqs[k].truesc - p->a)) c->active = 0; /* bwamem.c:1201 */
+			}
+			n_active += c->active;
+		}
+		if (n_active == 0) break;
+	}
+
+	for (k = 0; k < n_req; ++k) { /* NM / MD and the packed outputs */
+		cg_t *c = &cg[k];
+		size_t md_len = 0;
+		if (!c->valid) continue;
+		if (cig_used + (size_t)c->n_cigar > cigar_words || md_used + 3 * ((size_t)c->ql + (size_t)c->tl) + 16 > md_bytes) {
+			rc = BMH_E_CIGAR_CAP;
+			goto done;
+		}
+		memcpy(cigar_pool + cig_used, final_cig + c->fslot, 4 * (size_t)c->n_cigar);
+		res[k].NM = nm_md(c->n_cigar, cigar_pool + cig_used, pool + c->q_off, pool + c->t_off, c->rev, md_pool + md_used, &md_len);
+		res[k].score = c->score, res[k].n_cigar = c->n_cigar, res[k].tries = c->tries;
+		res[k].cigar_off = (uint32_t)cig_used, res[k].md_off = (uint32_t)md_used, res[k].md_len = (uint32_t)md_len;
+		cig_used += (size_t)c->n_cigar, md_used += md_len + 1;
+	}
+done:
+	free(cg), free(pool), free(tasks), free(gres), free(owner), free(scratch), free(final_cig);
+	return rc;
+}

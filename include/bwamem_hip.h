@@ -128,8 +128,9 @@ int bmh_global_batch(bmh_ctx_t *ctx, const uint8_t *seqpool, size_t pool_bytes,
                      const bmh_glb_task_t *tasks, int64_t n, bmh_glb_result_t *results,
                      uint32_t *cigar_pool, size_t cigar_pool_words);
 
-/* Leave a sequence pool resident on the device; afterwards bmh_extend_batch(ctx, NULL, 0, ...)
- * runs tasks against it without re-uploading (the L3 driver uploads once per read batch). */
+/* Leave a sequence pool resident on the device; afterwards bmh_extend_batch(ctx, NULL, 0, ...) and
+ * bmh_global_batch(ctx, NULL, 0, ...) run tasks against it without re-uploading (the L3 drivers
+ * upload once per batch and then only move task and result records per round). */
 int bmh_upload_pool(bmh_ctx_t *ctx, const uint8_t *seqpool, size_t pool_bytes);
 
 /* ---- L2, device-resident buffers: asynchronous on the context's stream.
@@ -206,6 +207,36 @@ typedef int (*bmh_chain_pre_fn)(void *user, int read, int chain, bmh_alnreg_v *a
 int bmh_chain2aln_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n_reads,
                         const bmh_read_t *reads, const bmh_chain_v *chains, bmh_chain_pre_fn pre,
                         void *pre_user, bmh_alnreg_v *regs);
+
+/* ---- L3, phase 2: the caller of ksw_global2.
+ * One request = one alignment region after bwa_fix_xref2, as mem_reg2aln sees it at bwamem.c:1187. */
+typedef struct bmh_cigar_req {
+	int32_t read;    /* index into reads[]                                              */
+	int32_t qb, qe;  /* query interval [qb,qe)                    (mem_alnreg_t.qb/qe)   */
+	int64_t rb, re;  /* reference interval, doubled coordinate    (mem_alnreg_t.rb/re)   */
+	int32_t truesc;  /* mem_alnreg_t.truesc: band inference + retry test, bwamem.c:1187,1201 */
+	int32_t reg_w;   /* mem_alnreg_t.w:      cap of the inferred band, bwamem.c:1191     */
+} bmh_cigar_req_t;
+
+typedef struct bmh_cigar_res {
+	int32_t score;      /* global alignment score of the last try (bwa_gen_cigar2 *score)   */
+	int32_t n_cigar;    /* number of CIGAR words                                             */
+	int32_t NM;         /* edit distance, bwa.c:162; -1 if the request was rejected (bwa.c:99) */
+	int32_t tries;      /* bwa_gen_cigar2 calls the reference would have made (1..3)          */
+	uint32_t cigar_off; /* first word in cigar_pool                                           */
+	uint32_t md_off;    /* first byte of the NUL-terminated MD string in md_pool              */
+	uint32_t md_len;    /* strlen(MD)                                                         */
+	uint32_t rsv_;
+} bmh_cigar_res_t;
+
+/* Replaces, for n_req regions at once, the loop of mem_reg2aln (bwamem.c:1187-1201) over
+ * bwa_gen_cigar2 (bwa.c:89-172): band inference, up to three banded global alignments per region
+ * (one GPU batch per try), NM and MD.  The reference appends the MD string to the CIGAR buffer
+ * (bwa.c:136,161-163); here both are returned separately -- INTEGRATION.md shows the two-line glue.
+ * Pools: cigar_words >= sum(qlen+tlen+2), md_bytes >= sum(3*(qlen+tlen)+16) always suffice. */
+int bmh_reg2cigar_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, const bmh_read_t *reads, int64_t n_req,
+                        const bmh_cigar_req_t *reqs, bmh_cigar_res_t *results, uint32_t *cigar_pool,
+                        size_t cigar_words, char *md_pool, size_t md_bytes);
 
 /* Counters of the last bmh_chain2aln_batch call (for the bench / logs). */
 typedef struct bmh_driver_stats {

@@ -84,8 +84,8 @@ def load_oracle():
     global _orc
     if _orc is None:
         path = os.path.join(ORACLE_DIR, "liborc.so")
-        srcs = [os.path.join(ORACLE_DIR, f) for f in ("ksw_oracle.c", "chain2aln_oracle.c",
-                                                      "ksw_oracle.h", "chain2aln_oracle.h")]
+        srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h"))]
+        srcs.append(os.path.join(ROOT, "include", "bwamem_hip.h"))
         if not os.path.exists(path) or any(os.path.getmtime(s) > os.path.getmtime(path) for s in srcs):
             _make("liborc.so")
         lib = C.CDLL(path)
@@ -270,3 +270,68 @@ def golden_chain2aln_groups():
     for k in sorted(per_group):
         items = per_group[k]
         yield g["params"][k], l_pac, pac, [x[0] for x in items], [x[1] for x in items], [x[2] for x in items]
+
+
+# ---- phase 2: CIGAR generation (row a6) ---------------------------------------
+CIGAR_REQ = np.dtype([("read", "<i4"), ("qb", "<i4"), ("qe", "<i4"), ("pad", "<i4"), ("rb", "<i8"), ("re", "<i8"),
+                      ("truesc", "<i4"), ("reg_w", "<i4")])
+
+
+class _OrcCigar(C.Structure):
+    _fields_ = [("score", C.c_int), ("n_cigar", C.c_int), ("NM", C.c_int), ("w_used", C.c_int),
+                ("cigar", C.POINTER(C.c_uint32)), ("md", C.c_char_p)]
+
+
+def orc_reg2cigar(p, l_pac, pac, read, req):
+    """OUR restatement of mem_reg2aln's band/retry loop over bwa_gen_cigar2: (score, cigar words, NM, MD, tries)."""
+    lib = load_oracle()
+    lib.orc_reg2cigar.restype = None
+    pp = np.ascontiguousarray(np.asarray(p, dtype=PARAMS).reshape(()))
+    pac = np.ascontiguousarray(pac, dtype=np.uint8)
+    read = np.ascontiguousarray(read, dtype=np.uint8)
+    o, rounds = _OrcCigar(), C.c_int(0)
+    lib.orc_reg2cigar(pp.ctypes.data_as(C.c_void_p), C.c_int64(l_pac), pac.ctypes.data_as(C.c_void_p),
+                      read.ctypes.data_as(C.c_void_p), C.c_int(int(req["qb"])), C.c_int(int(req["qe"])),
+                      C.c_int64(int(req["rb"])), C.c_int64(int(req["re"])), C.c_int(int(req["truesc"])),
+                      C.c_int(int(req["reg_w"])), C.byref(o), C.byref(rounds))
+    words = np.array([o.cigar[i] for i in range(o.n_cigar)], dtype=np.uint32)
+    md = bytes(o.md) if o.md else b""
+    res = (o.score, words, o.NM, md, rounds.value)
+    lib.orc_cigar_free(C.byref(o))
+    return res
+
+
+def finish_aln(words, md, req, l_query, l_pac):
+    """What mem_reg2aln does AFTER the CIGAR loop (reference bwamem.c:1202-1230), so that the loop's output can
+    be compared with the reference's mem_aln_t: drop a leading/trailing deletion, add soft clips."""
+    words = [int(x) for x in words]
+    is_rev = int(req["rb"]) >= l_pac
+    if words:
+        if words[0] & 0xf == 2:
+            words = words[1:]
+        elif words[-1] & 0xf == 2:
+            words = words[:-1]
+    qb, qe = int(req["qb"]), int(req["qe"])
+    if qb != 0 or qe != l_query:
+        clip5 = l_query - qe if is_rev else qb
+        clip3 = qb if is_rev else l_query - qe
+        if clip5:
+            words = [clip5 << 4 | 3] + words
+        if clip3:
+            words = words + [clip3 << 4 | 3]
+    return np.array(words, dtype=np.uint32), md
+
+
+def golden_cigar_groups():
+    """Yields (params, l_pac, pac, reads, reqs, expected) per parameter set of cigar_golden.npz;
+    expected = list of (n_cigar, words, NM, md_bytes) from the reference's own mem_reg2aln."""
+    g = load_golden("cigar_golden.npz")
+    l_pac, pac = int(g["l_pac"]), g["pac"]
+    ro, rp = g["read_off"], g["read_pool"]
+    reads = [rp[ro[r]:ro[r + 1]] for r in range(len(ro) - 1)]
+    mds = bytes(g["exp_md"]).split(b"\0")
+    woff = np.concatenate([[0], np.cumsum(g["exp_n_cigar"])])
+    for k in range(len(g["params"])):
+        sel = np.nonzero(g["group"] == k)[0]
+        exp = [(int(g["exp_n_cigar"][i]), g["exp_cigar"][woff[i]:woff[i + 1]], int(g["exp_nm"][i]), mds[i]) for i in sel]
+        yield g["params"][k], l_pac, pac, reads, g["reqs"][sel], exp

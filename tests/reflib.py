@@ -143,3 +143,26 @@ def pac_of(idx):
     l_pac = idx.contents.bns.contents.l_pac
     n = l_pac // 4 + 1
     return int(l_pac), np.ctypeslib.as_array(idx.contents.pac, shape=(n,)).copy()
+
+
+class MemAln(C.Structure):  # mem_aln_t, bwamem.h:72-82
+    _fields_ = [("pos", C.c_int64), ("rid", C.c_int), ("flag", C.c_int), ("bits", C.c_uint32), ("n_cigar", C.c_int),
+                ("cigar", C.POINTER(C.c_uint32)), ("score", C.c_int), ("sub", C.c_int)]
+
+
+def ref_reg2aln(idx, opt, read, reg):
+    """The reference's own mem_reg2aln (bwamem.c:1164-1236) on one region.  Returns
+    (n_cigar, cigar words incl. clipping, NM, MD string, is_rev, pos)."""
+    L = lib()
+    L.mem_reg2aln.restype = MemAln
+    L.mem_reg2aln.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    seq = np.ascontiguousarray(read, dtype=np.uint8)
+    ar = np.ascontiguousarray(np.asarray(reg, dtype=kswlib.ALNREG).reshape(()))
+    a = L.mem_reg2aln(opt, idx.contents.bns, idx.contents.pac, len(seq), seq.ctypes.data_as(C.c_void_p),
+                      ar.ctypes.data_as(C.c_void_p))
+    words = np.array([a.cigar[i] for i in range(a.n_cigar)], dtype=np.uint32)
+    md = C.string_at(C.cast(a.cigar, C.c_void_p).value + 4 * a.n_cigar) if a.n_cigar or a.cigar else b""
+    out = (a.n_cigar, words, (a.bits >> 9) & 0x7fffff, md, a.bits & 1, a.pos)
+    if a.cigar:
+        _libc.free(C.cast(a.cigar, C.c_void_p))
+    return out

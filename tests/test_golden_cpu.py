@@ -50,3 +50,18 @@ def test_fixture_coverage_matrix():
     assert (e["gscore"] == -1).any() and (e["gscore"] > 0).any() and (e["tle"] == 0).any()
     assert ((t["flags"] & 1) > 0).any() and ((t["flags"] & 2) > 0).any()
     assert (t["tlen"].astype(int) > t["qlen"].astype(int) + t["w"].astype(int)).sum() > 100  # empty-row territory
+
+
+def test_oracle_reg2cigar_matches_reference_mem_reg2aln_fixture():
+    """orc_reg2cigar (band inference + retry loop + bwa_gen_cigar2 restatement) followed by the reference's
+    post-processing (clipping, terminal deletions) == the reference's own mem_reg2aln."""
+    n = 0
+    for p, l_pac, pac, reads, reqs, exp in kswlib.golden_cigar_groups():
+        for rq, (en, ew, enm, emd) in zip(reqs, exp):
+            read = reads[int(rq["read"])]
+            score, words, nm, md, tries = kswlib.orc_reg2cigar(p, l_pac, pac, read, rq)
+            fw, fmd = kswlib.finish_aln(words, md, rq, len(read), l_pac)
+            assert len(fw) == en and np.array_equal(fw, ew), f"req {rq}: {fw} vs {ew}"
+            assert nm == enm and fmd == emd
+            n += 1
+    assert n >= 2000

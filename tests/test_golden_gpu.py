@@ -53,3 +53,25 @@ def test_hip_chain2aln_driver_matches_reference_fixture(ctx):
         st = ctx.driver_stats()
         assert st["rounds"] >= 2 and st["ext_tasks"] > 0
     assert nreg >= 2500
+
+
+def test_hip_reg2cigar_driver_matches_reference_fixture(ctx):
+    """bmh_reg2cigar_batch (batched GPU rounds) == the reference's mem_reg2aln (CIGAR, NM, MD), and == the oracle
+    on score and number of tries."""
+    n = 0
+    for p, l_pac, pac, reads, reqs, exp in kswlib.golden_cigar_groups():
+        ctx.set_params(p)
+        res, cig, md = ctx.reg2cigar_batch(l_pac, pac, reads, reqs)
+        mdb = bytes(md)
+        for rq, r, (en, ew, enm, emd) in zip(reqs, res, exp):
+            words = cig[int(r["cigar_off"]): int(r["cigar_off"]) + int(r["n_cigar"])]
+            m = mdb[int(r["md_off"]): int(r["md_off"]) + int(r["md_len"])]
+            read = reads[int(rq["read"])]
+            fw, fmd = kswlib.finish_aln(words, m, rq, len(read), l_pac)
+            assert len(fw) == en and np.array_equal(fw, ew), f"req {rq}: gpu={fw} ref={ew}"
+            assert int(r["NM"]) == enm and fmd == emd
+            if n % 50 == 0:
+                oscore, _, _, _, otries = kswlib.orc_reg2cigar(p, l_pac, pac, read, rq)
+                assert int(r["score"]) == oscore and int(r["tries"]) == otries
+            n += 1
+    assert n >= 2000

@@ -150,11 +150,53 @@ def make_chain2aln():
           int((np.array(read_nchains) > 1).sum()), "reads with >1 chain")
 
 
+def make_cigar():
+    """Regions = what the reference's own mem_chain2aln produced for the chain2aln fixture; expected = the reference's
+    own mem_reg2aln on each of them (CIGAR incl. clipping, NM, MD)."""
+    rng = np.random.default_rng(20261008)
+    tmp = tempfile.mkdtemp(prefix="bmh_golden_cig_")
+    ref = kswgen.rand_seq(rng, 150000)
+    for _ in range(10):
+        a, b, L = int(rng.integers(0, 140000)), int(rng.integers(0, 140000)), int(rng.integers(200, 600))
+        ref[b:b + L] = kswgen.mutate(rng, ref[a:a + L + 20], 0.03, 0.002, 0.002, 2)[:L]
+    fa = os.path.join(tmp, "ref.fa")
+    reflib.write_fasta(fa, "synth", ref)
+    reflib.build_index(fa)
+    idx = reflib.lib().bwa_idx_load(fa.encode(), 7)
+    l_pac, pac = reflib.pac_of(idx)
+    psets = [kswlib.make_params(), kswlib.make_params(w=10, zdrop=30),
+             kswlib.make_params(a=2, b=6, o_del=8, o_ins=6, e_del=2, e_ins=3, zdrop=200, pen_clip5=10, pen_clip3=10)]
+    out = dict(l_pac=np.int64(l_pac), pac=pac, params=np.array(psets, dtype=kswlib.PARAMS))
+    read_pool, read_off, reqs, grp, exp_n, exp_words, exp_nm, exp_md = [], [0], [], [], [], [], [], []
+    nread = 0
+    for g, p in enumerate(psets):
+        opt = reflib.opt_from_params(p)
+        reads = sim_reads(rng, ref, 350, (150, 150), False) + sim_reads(rng, ref, 250, (100, 300), True)
+        chains, regs = reflib.chains_and_regs(idx, opt, reads)
+        for r, rg in zip(reads, regs):
+            read_pool.append(r), read_off.append(read_off[-1] + len(r))
+            for a in rg:
+                if a["rb"] < 0 or a["score"] < 20:
+                    continue
+                n, words, nm, md, is_rev, pos = reflib.ref_reg2aln(idx, opt, r, a)
+                reqs.append((nread, int(a["qb"]), int(a["qe"]), 0, int(a["rb"]), int(a["re"]), int(a["truesc"]), int(a["w"])))
+                grp.append(g), exp_n.append(n), exp_words.append(words), exp_nm.append(nm), exp_md.append(md + b"\0")
+            nread += 1
+    out.update(read_pool=np.concatenate(read_pool), read_off=np.array(read_off, np.int64),
+               reqs=np.array(reqs, dtype=kswlib.CIGAR_REQ), group=np.array(grp, np.int32),
+               exp_n_cigar=np.array(exp_n, np.int32), exp_cigar=np.concatenate(exp_words),
+               exp_nm=np.array(exp_nm, np.int32), exp_md=np.frombuffer(b"".join(exp_md), dtype=np.uint8))
+    np.savez_compressed(os.path.join(OUT, "cigar_golden.npz"), **out)
+    rev = int((out["reqs"]["rb"] >= l_pac).sum())
+    print("cigar_golden:", len(reqs), "regions,", rev, "on the reverse strand,", int((np.array(exp_nm) > 5).sum()), "with NM>5")
+
+
 if __name__ == "__main__":
     assert kswlib.have_ref() and reflib.have_ref_bwa(), "build oracle/_ref first (make -C oracle)"
     os.makedirs(OUT, exist_ok=True)
     make_ext()
     make_glb()
     make_chain2aln()
+    make_cigar()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)), "bytes")
