@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--workload", default="150bp", choices=["150bp", "mixed100-300"])
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--global-tasks", type=int, default=250_000,
+                    help="size of the secondary ksw_global2 measurement (0 = skip); rank 0 at N=1 only")
     args = ap.parse_args()
 
     import torch
@@ -104,6 +106,52 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed, reads_all, tasks_all = sh.reduce_report(elapsed, n_reads_used, n_tasks, dev)
+
+    # ---- secondary measurement: the banded global alignment + traceback kernel (row a2), N=1 only
+    glb = None
+    if world == 1 and args.global_tasks > 0:
+        gpool, gtasks, gwords = tg.generate_global(args.global_tasks, args.workload, seed=11)
+        dg_pool = torch.from_numpy(gpool).to(dev)
+        dg_tasks = torch.from_numpy(gtasks.view(np.uint8)).to(dev)
+        dg_res = torch.zeros(len(gtasks) * pkg.GLB_RES.itemsize, dtype=torch.uint8, device=dev)
+        dg_cig = torch.zeros(gwords + 4, dtype=torch.int32, device=dev)
+        ctx.set_qcap(int(max(gtasks["qlen"].max(), tasks["qlen"].max())))
+        gsteps = max(3, args.steps // 4)
+        with torch.cuda.stream(stream):
+            ctx.global_batch_device(dg_pool.data_ptr(), dg_tasks.data_ptr(), len(gtasks), dg_res.data_ptr(), dg_cig.data_ptr())
+            torch.cuda.synchronize(dev)
+            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            g0.record(stream)
+            for _ in range(gsteps):
+                ctx.global_batch_device(dg_pool.data_ptr(), dg_tasks.data_ptr(), len(gtasks), dg_res.data_ptr(),
+                                        dg_cig.data_ptr())
+            g1.record(stream)
+            torch.cuda.synchronize(dev)
+        ctx.sync()
+        g_ms = g0.elapsed_time(g1) / gsteps
+        gres = dg_res.cpu().numpy().view(pkg.GLB_RES)
+        gcig = dg_cig.cpu().numpy().view(np.uint32)
+        ncores = os.cpu_count() or 1
+        ns = min(len(gtasks), 100000)
+        t1 = time.perf_counter()
+        ores, ocig, ocells = kswlib.orc_global_batch_mt(params, gpool, gtasks[:ns], gwords, nthreads=ncores)
+        t1 = time.perf_counter()
+        ores, ocig, ocells = kswlib.orc_global_batch_mt(params, gpool, gtasks[:ns], gwords, nthreads=ncores)
+        g_cpu_dt = time.perf_counter() - t1
+        ok = bool((ores == gres[:ns]).all())
+        for k in range(0, ns, 97):
+            o, nn = int(gtasks[k]["cigar_off"]), int(ores[k]["n_cigar"])
+            ok = ok and bool((ocig[o:o + nn] == gcig[o:o + nn]).all())
+        band_cells = float((np.minimum(gtasks["qlen"].astype(np.int64), 2 * gtasks["w"].astype(np.int64) + 1)
+                            * gtasks["tlen"].astype(np.int64)).sum())
+        g_bytes = float(gtasks["qlen"].astype(np.int64).sum() + gtasks["tlen"].astype(np.int64).sum()
+                        + 40 * len(gtasks) + 4 * gres["n_cigar"].astype(np.int64).sum())
+        glb = {"kernel": "global_kernel (ksw_global2 + traceback)", "tasks": int(len(gtasks)), "ms": g_ms,
+               "tasks_per_s": len(gtasks) / (g_ms * 1e-3), "band_gcups": band_cells / (g_ms * 1e-3) / 1e9,
+               "algorithmic_GBps": g_bytes / (g_ms * 1e-3) / 1e9, "mean_w": float(gtasks["w"].mean()),
+               "parity": "bit-exact vs oracle (scores, n_cigar, sampled CIGARs)" if ok else "MISMATCH vs oracle",
+               "cpu_port_tasks_per_s": ns / g_cpu_dt, "cpu_threads": ncores}
+        del dg_pool, dg_tasks, dg_res, dg_cig
 
     # ---- parity spot-check + CPU baseline (untimed w.r.t. the GPU figure)
     res = d_res.cpu().numpy().view(pkg.EXT_RES)
@@ -191,6 +239,7 @@ def main():
                                  "algorithmic byte vs ~5 ops/B machine balance, SURVEY.md §8d); the HBM fraction "
                                  "is reported because the contract asks for it, GCUPS is the honest figure"},
             "cpu_baseline": cpu,
+            "global_alignment": glb,
             "setup": {"taskgen_s": gen_s},
         }
         if not parity_ok:

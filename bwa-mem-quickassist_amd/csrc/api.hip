@@ -116,6 +116,7 @@ int bmh_ctx_create(bmh_ctx_t **out, int device)
 	}
 	ctx->stream = ctx->own_stream;
 	if (const char *m = getenv("BMH_EXT_MODE")) ctx->force_kernel = !strcmp(m, "lds") ? 1 : !strcmp(m, "reg") ? 2 : !strcmp(m, "grp") ? 3 : 0;
+	if (const char *m = getenv("BMH_GLB_MODE")) ctx->glb_mode = !strcmp(m, "wave") ? 1 : 0;
 	if (const char *m = getenv("BMH_GRID_MULT")) ctx->grid_mult = atoi(m) > 0 ? atoi(m) : 1;
 	*out = ctx;
 	return BMH_OK;
@@ -127,7 +128,7 @@ int bmh_ctx_destroy(bmh_ctx_t *ctx)
 	(void)hipSetDevice(ctx->device);
 	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 	free_buf(ctx->d_pool), free_buf(ctx->d_tasks), free_buf(ctx->d_res), free_buf(ctx->d_order);
-	free_buf(ctx->d_cigar), free_buf(ctx->d_scratch), free_buf(ctx->d_bins);
+	free_buf(ctx->d_cigar), free_buf(ctx->d_scratch), free_buf(ctx->d_bins), free_buf(ctx->d_zslab);
 	if (ctx->d_err) (void)hipFree(ctx->d_err);
 	if (ctx->h_err) (void)hipHostFree(ctx->h_err);
 	if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);

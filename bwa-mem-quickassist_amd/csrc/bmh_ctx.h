@@ -21,6 +21,8 @@ struct bmh_ctx {
 	int qcap = 512; // query-length capacity used to size the LDS kernel's window state for *_device calls
 	// device workspaces of the host-buffer entry points
 	DevBuf d_pool, d_tasks, d_res, d_order, d_cigar, d_scratch;
+	DevBuf d_zslab; // direction words of the lane-per-task global kernels, one slab per resident wave
+	int glb_mode = 0; // 0 lane-per-task global kernels, 1 one wave per task only (env BMH_GLB_MODE=wave)
 	DevBuf d_bins; // per-launch bin lists of the extension dispatcher: 4 counters + 4 x n task indices
 	int grid_mult = 1;    // env BMH_GRID_MULT: persistent grid = resident waves x this (tuning knob)
 	int force_kernel = 0; // kernels for qlen<=128: 0 lane-per-task, 1 LDS kernel, 2 one task/wave, 3 four tasks/wave (env BMH_EXT_MODE=lds|reg|grp)
@@ -59,6 +61,12 @@ int launch_extend(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_t
                   bmh_ext_result_t *d_res, const uint32_t *d_order, int qmax);
 int launch_extend_lds(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
                       bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, int qmax);
+constexpr int kSortKeysHost = 2048; // == kSortKeys in extend_dispatch.hip
+int sort_tasks_begin(bmh_ctx *ctx, int64_t n, uint32_t **counts, uint32_t **lists);
+int sort_tasks_finish(bmh_ctx *ctx, int64_t n, const uint32_t *d_order, unsigned blocks);
+int launch_global_lane(bmh_ctx *ctx, int c, const uint8_t *d_pool, const bmh_glb_task_t *d_tasks, int64_t n,
+                       bmh_glb_result_t *d_res, uint32_t *d_cigar, const uint32_t *d_order, const uint32_t *d_count,
+                       int rows_cap);
 constexpr int kExtBins = 5;        // length bins of the extension dispatcher
 constexpr int kGrpTcapHost = 1024; // == kGrpTcap in extend_grp.hip
 int launch_extend_grp(bmh_ctx *ctx, int nv, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,

@@ -113,6 +113,32 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint32
 	}
 }
 
+// shared by the extension and the global dispatchers: workspace layout + the scan/scatter passes
+static_assert(kSortKeys == kSortKeysHost, "keep bmh_ctx.h in sync");
+int sort_tasks_begin(bmh_ctx *ctx, int64_t n, uint32_t **counts, uint32_t **lists)
+{
+	const size_t N = (size_t)n, hist_words = (size_t)kExtBins * kSortKeys;
+	int rc = ensure(ctx, ctx->d_bins, (16 + hist_words + (N + 1) / 2 + 1 + (size_t)kExtBins * N) * 4);
+	if (rc) return rc;
+	*counts = (uint32_t *)ctx->d_bins.p;
+	*lists = *counts + 16 + hist_words + (N + 1) / 2 + 1;
+	BMH_HIP(ctx, hipMemsetAsync(*counts, 0, (16 + hist_words) * 4, ctx->stream));
+	return BMH_OK;
+}
+
+int sort_tasks_finish(bmh_ctx *ctx, int64_t n, const uint32_t *d_order, unsigned blocks)
+{
+	const size_t N = (size_t)n, hist_words = (size_t)kExtBins * kSortKeys;
+	uint32_t *counts = (uint32_t *)ctx->d_bins.p, *hist = counts + 16;
+	uint16_t *binkey = (uint16_t *)(hist + hist_words);
+	uint32_t *lists = hist + hist_words + (N + 1) / 2 + 1;
+	hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, hist, counts);
+	hipLaunchKernelGGL(sort_scatter_kernel, dim3(blocks), dim3(kSortThreads), 0, ctx->stream, d_order, (long long)n, hist, binkey,
+	                   lists);
+	BMH_HIP(ctx, hipGetLastError());
+	return BMH_OK;
+}
+
 int launch_extend(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
                   bmh_ext_result_t *d_res, const uint32_t *d_order, int qmax)
 {
@@ -120,21 +146,15 @@ int launch_extend(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_t
 	int rc;
 	const int mode = ctx->force_kernel; // 0 lane-per-task, 1 lds, 2 reg (1 task/wave), 3 grp (4 tasks/wave)
 	const size_t N = (size_t)n;
-	const size_t hist_words = (size_t)kExtBins * kSortKeys;
-	if ((rc = ensure(ctx, ctx->d_bins, (16 + hist_words + (N + 1) / 2 + 1 + (size_t)kExtBins * N) * 4))) return rc;
-	uint32_t *counts = (uint32_t *)ctx->d_bins.p;
+	uint32_t *counts, *lists;
+	if ((rc = sort_tasks_begin(ctx, n, &counts, &lists))) return rc;
 	uint32_t *hist = counts + 16;
-	uint16_t *binkey = (uint16_t *)(hist + hist_words);
-	uint32_t *lists = hist + hist_words + (N + 1) / 2 + 1;
-	BMH_HIP(ctx, hipMemsetAsync(counts, 0, (16 + hist_words) * 4, ctx->stream));
+	uint16_t *binkey = (uint16_t *)(hist + (size_t)kExtBins * kSortKeys);
 	long long cg = (n + 1023) / 1024;
 	if (cg > kSortBlocks) cg = kSortBlocks;
 	hipLaunchKernelGGL(sort_hist_kernel, dim3((unsigned)cg), dim3(kSortThreads), 0, ctx->stream, d_tasks, d_order, (long long)n,
 	                   hist, binkey, mode);
-	hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, hist, counts);
-	hipLaunchKernelGGL(sort_scatter_kernel, dim3((unsigned)cg), dim3(kSortThreads), 0, ctx->stream, d_order, (long long)n, hist,
-	                   binkey, lists);
-	BMH_HIP(ctx, hipGetLastError());
+	if ((rc = sort_tasks_finish(ctx, n, d_order, (unsigned)cg))) return rc;
 	const bool tm = ctx->timing;
 	if (tm) BMH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
 	for (int b = 0; b < kExtBins; ++b) {

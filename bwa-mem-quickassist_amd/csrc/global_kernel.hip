@@ -45,7 +45,8 @@ struct CigarSink { // wave-uniform run-length CIGAR builder writing backwards fr
 template <bool ZLDS>
 __global__ __launch_bounds__(64) void global_kernel(const uint8_t *__restrict__ pool,
                                                     const bmh_glb_task_t *__restrict__ tasks,
-                                                    const uint32_t *__restrict__ order, long long n,
+                                                    const uint32_t *__restrict__ order,
+                                                    const uint32_t *__restrict__ count, long long n,
                                                     bmh_glb_result_t *__restrict__ out,
                                                     uint32_t *__restrict__ cigar_pool, DevParams P, int qcap,
                                                     long long zcap, uint8_t *__restrict__ zscratch,
@@ -64,6 +65,7 @@ __global__ __launch_bounds__(64) void global_kernel(const uint8_t *__restrict__ 
 
 	if (lane < 25) smat[lane] = (int8_t)mat_at(P, lane);
 
+	if (count) n = *count; // bin size produced on the device by the dispatcher
 	for (long long slot = blockIdx.x; slot < n; slot += gridDim.x) {
 		const uint32_t idx = order ? order[slot] : (uint32_t)slot;
 		const uint4 *tp = (const uint4 *)(tasks + idx);
@@ -204,40 +206,88 @@ __global__ __launch_bounds__(64) void global_kernel(const uint8_t *__restrict__ 
 	}
 }
 
-// ---- launcher ---------------------------------------------------------------------------
-// LDS per block = 16 B/column state+profile (+ the direction matrix when it fits beside it).
+// ---- dispatcher -----------------------------------------------------------------------------------
+// bin 0: w <= 31  -> global_lane_kernel<64>   (64 tasks per wave, band-relative registers)
+// bin 1: w <= 63  -> global_lane_kernel<128>
+// bin 2: wider bands, targets longer than the lane kernels' direction slab, or scores that could leave the
+//        16-bit range -> global_kernel (one wave per task, int32 in LDS)
+// Bins and the order inside them (by row count) come from the same device-side counting sort as the extension path.
+__global__ __launch_bounds__(256) void glb_sort_hist_kernel(const bmh_glb_task_t *__restrict__ tasks,
+                                                            const uint32_t *__restrict__ order, long long n,
+                                                            uint32_t *__restrict__ hist, uint16_t *__restrict__ binkey,
+                                                            DevParams P, int lane_ok, int rows_cap)
+{
+	__shared__ uint32_t lh[kExtBins * kSortKeysHost];
+	for (int t = threadIdx.x; t < kExtBins * kSortKeysHost; t += 256) lh[t] = 0;
+	__syncthreads();
+	const long long chunk = (n + gridDim.x - 1) / gridDim.x, lo = chunk * blockIdx.x, hi = min(lo + chunk, n);
+	const int emax = max(P.e_del, P.e_ins), smax = max(P.bias, P.max_mat);
+	for (long long k = lo + threadIdx.x; k < hi; k += 256) {
+		const uint32_t idx = order ? order[k] : (uint32_t)k;
+		const int qlen = tasks[idx].qlen, tlen = tasks[idx].tlen, w = tasks[idx].w;
+		const int worst = P.o_del + P.o_ins + emax * (qlen + tlen) + smax * max(qlen, tlen); // |score| bound of any cell
+		int bin = 2;
+		if (lane_ok && tlen <= rows_cap && worst < 12000 && w >= 0) bin = w <= 31 ? 0 : (w <= 63 ? 1 : 2);
+		const int bk = bin * kSortKeysHost + (bin < 2 ? min(tlen >> 1, kSortKeysHost - 1) : 0);
+		binkey[k] = (uint16_t)bk;
+		atomicAdd(&lh[bk], 1u);
+	}
+	__syncthreads();
+	for (int t = threadIdx.x; t < kExtBins * kSortKeysHost; t += 256)
+		if (lh[t]) atomicAdd(&hist[t], lh[t]);
+}
+
 int launch_global(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_glb_task_t *d_tasks, int64_t n,
                   bmh_glb_result_t *d_res, uint32_t *d_cigar, const uint32_t *d_order, int qmax, int tmax,
                   int wmax)
 {
 	if (n <= 0) return BMH_OK;
-	const int qcap = (qmax + 63) & ~63;
-	const size_t state = (size_t)8 * (qcap + 2) + (size_t)8 * qcap + 32;
-	const long long ncol = qmax < 2LL * wmax + 1 ? qmax : 2LL * wmax + 1;
-	long long zcap = ncol * (long long)tmax;
-	zcap = (zcap + 15) & ~15LL;
-	if (zcap < 16) zcap = 16;
-	if (state > 160 * 1024) return BMH_E_RANGE;
-	const bool zlds = state + (size_t)zcap <= 64 * 1024; // keep >= 2 blocks per CU in the LDS variant
-	long long grid = n < (1LL << 30) ? n : (1LL << 30);
+	int rc;
+	const size_t N = (size_t)n;
+	const bool lane_ok = ctx->glb_mode == 0;
+	const int rows_cap = tmax < 512 ? tmax : 512; // rows of the lane kernels' direction slab
+	uint32_t *counts, *lists;
+	if ((rc = sort_tasks_begin(ctx, n, &counts, &lists))) return rc;
+	uint32_t *hist = counts + 16;
+	uint16_t *binkey = (uint16_t *)(hist + (size_t)kExtBins * kSortKeysHost);
+	long long cg = (n + 1023) / 1024;
+	if (cg > 512) cg = 512;
+	hipLaunchKernelGGL(glb_sort_hist_kernel, dim3((unsigned)cg), dim3(256), 0, ctx->stream, d_tasks, d_order, (long long)n, hist,
+	                   binkey, ctx->dev, lane_ok ? 1 : 0, rows_cap);
+	if ((rc = sort_tasks_finish(ctx, n, d_order, (unsigned)cg))) return rc;
 	if (ctx->timing) BMH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-	if (zlds) {
-		hipLaunchKernelGGL(global_kernel<true>, dim3((unsigned)grid), dim3(64), state + (size_t)zcap, ctx->stream,
-		                   d_pool, d_tasks, d_order, (long long)n, d_res, d_cigar, ctx->dev, qcap, zcap,
-		                   (uint8_t *)nullptr, ctx->d_err);
-	} else {
-		long long budget = 8LL << 30; // HBM scratch for direction bytes, one slab per resident block
-		long long g = budget / zcap;
-		if (g < 1) return BMH_E_RANGE;
-		if (g > 8192) g = 8192;
-		if (grid > g) grid = g;
-		int rc = ensure(ctx, ctx->d_scratch, (size_t)grid * (size_t)zcap);
-		if (rc) return rc;
-		hipLaunchKernelGGL(global_kernel<false>, dim3((unsigned)grid), dim3(64), state, ctx->stream, d_pool, d_tasks,
-		                   d_order, (long long)n, d_res, d_cigar, ctx->dev, qcap, zcap, (uint8_t *)ctx->d_scratch.p,
-		                   ctx->d_err);
+	if (lane_ok) {
+		if ((rc = launch_global_lane(ctx, 64, d_pool, d_tasks, n, d_res, d_cigar, lists, counts + 0, rows_cap))) return rc;
+		if (wmax > 31 && (rc = launch_global_lane(ctx, 128, d_pool, d_tasks, n, d_res, d_cigar, lists + N, counts + 1, rows_cap)))
+			return rc;
 	}
-	BMH_HIP(ctx, hipGetLastError());
+	{ // bin 2: the wave kernel
+		const uint32_t *lst = lists + 2 * N, *cnt = counts + 2;
+		const int qcap = (qmax + 63) & ~63;
+		const size_t state = (size_t)8 * (qcap + 2) + (size_t)8 * qcap + 32;
+		const long long ncol = qmax < 2LL * wmax + 1 ? qmax : 2LL * wmax + 1;
+		long long zcap = ncol * (long long)tmax;
+		zcap = (zcap + 15) & ~15LL;
+		if (zcap < 16) zcap = 16;
+		if (state > 160 * 1024) return BMH_E_RANGE;
+		const bool zlds = state + (size_t)zcap <= 64 * 1024; // keep >= 2 blocks per CU in the LDS variant
+		long long grid = n < (1LL << 20) ? n : (1LL << 20);
+		if (lane_ok && grid > 8192) grid = 8192; // normally (almost) empty when the lane kernels are on
+		if (zlds) {
+			hipLaunchKernelGGL(global_kernel<true>, dim3((unsigned)grid), dim3(64), state + (size_t)zcap, ctx->stream, d_pool,
+			                   d_tasks, lst, cnt, (long long)n, d_res, d_cigar, ctx->dev, qcap, zcap, (uint8_t *)nullptr, ctx->d_err);
+		} else {
+			long long budget = 8LL << 30; // HBM scratch for direction bytes, one slab per resident block
+			long long g = budget / zcap;
+			if (g < 1) return BMH_E_RANGE;
+			if (g > 8192) g = 8192;
+			if (grid > g) grid = g;
+			if ((rc = ensure(ctx, ctx->d_scratch, (size_t)grid * (size_t)zcap))) return rc;
+			hipLaunchKernelGGL(global_kernel<false>, dim3((unsigned)grid), dim3(64), state, ctx->stream, d_pool, d_tasks, lst, cnt,
+			                   (long long)n, d_res, d_cigar, ctx->dev, qcap, zcap, (uint8_t *)ctx->d_scratch.p, ctx->d_err);
+		}
+		BMH_HIP(ctx, hipGetLastError());
+	}
 	if (ctx->timing) {
 		BMH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
 		ctx->ev_valid = true;

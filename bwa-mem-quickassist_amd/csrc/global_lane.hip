@@ -1,0 +1,246 @@
+// global_lane.hip -- banded global alignment + traceback, 64 tasks per wave64 (one lane per task).
+//
+// Same results as ksw_global2 (reference bwa-0.7.8/ksw.c:501-584) and as global_kernel (one wave per task).
+// The band of ksw_global2 is FIXED: row i covers columns [max(0,i-w), min(qlen,i+w+1)) (ksw.c:528-529).  So the
+// row state is kept BAND-RELATIVE: slot s of row i is column j = i-w+s, 0 <= s <= 2w.  In these coordinates
+//     the diagonal predecessor (i-1,j-1) is slot s   of the previous row  -> H is updated in place,
+//     the vertical predecessor (i-1,j)   is slot s+1 of the previous row  -> E is read from the next register,
+//     the horizontal predecessor (i,j-1) is slot s-1 of the same row      -> F is carried through the unrolled slots,
+// and C = 64 (w <= 31) or 128 (w <= 63) registers hold the row of a task of ANY length: register s packs
+// {H(i-1,j-1), E(i,j-1)} as two signed 16-bit halves (one v_perm_b32 to re-pack).  The query slides by one base per
+// row: its v_perm selectors sit four per VGPR and the whole window is funnel-shifted by one byte per row
+// (v_alignbyte_b32, C/4 instructions), the new byte coming from a per-lane global load issued one row ahead.
+// Inactive slots are refilled every row with the first-column value -(o_del+e_del*(i+1)) (ksw.c:530) -- the slot just
+// left of the band is the virtual column -1 that the next row's column 0 reads diagonally -- or with -inf.
+// "-inf" is -16384: every comparison of the reference that involves MINUS_INF (ksw.c:487) has a finite value on the
+// other side (a cell inside the band always has an in-band diagonal predecessor), so any sentinel below all finite
+// scores reproduces it; the dispatcher sends tasks whose scores could reach -12000 to the int32 wave kernel.
+// Direction bytes (same encoding as ksw.c:547-561) are packed four per dword and written to a per-wave HBM slab
+// laid out [row][slot/4][lane], so both the stores of the fill and the loads of the per-lane traceback coalesce.
+// The traceback (ksw.c:566-581) is the reference's loop, one path per lane, CIGAR words written by the lane itself.
+#include "bmh_ctx.h"
+#include "bmh_device.h"
+
+namespace bmh {
+
+constexpr int kNeg16 = -16384;
+
+__device__ __forceinline__ int sel3(int mask, int a, int b) { return __builtin_amdgcn_bitop3_b32(mask, a, b, 0xca); }
+
+template <int C>
+__global__ __launch_bounds__(64, (C <= 64 ? 3 : 2)) void global_lane_kernel(
+    const uint8_t *__restrict__ pool, const bmh_glb_task_t *__restrict__ tasks, const uint32_t *__restrict__ order,
+    const uint32_t *__restrict__ count, long long n, bmh_glb_result_t *__restrict__ out, uint32_t *__restrict__ cigar_pool,
+    DevParams P, uint32_t *__restrict__ zslab, int rows_cap, int *__restrict__ err_flag)
+{
+	constexpr int NW = C / 32, NQ = C / 4, NB = C / 8;
+	__shared__ uint2 srow[8];
+	const int lane = threadIdx.x;
+	const int oe_del = P.o_del + P.e_del, oe_ins = P.o_ins + P.e_ins;
+	const int e_del = P.e_del, e_ins = P.e_ins;
+	if (lane < 5) {
+		uint32_t lo = 0;
+		for (int q = 0; q < 4; ++q) lo |= (uint32_t)(uint8_t)mat_at(P, lane * 5 + q) << (8 * q);
+		srow[lane] = make_uint2(lo, (uint32_t)(uint8_t)mat_at(P, lane * 5 + 4));
+	}
+	const long long cnt = count ? (long long)*count : n;
+	uint32_t *__restrict__ zw = zslab + (size_t)blockIdx.x * (size_t)rows_cap * (size_t)(NQ * 64) + lane;
+
+	for (long long base = (long long)blockIdx.x * 64; base < cnt; base += (long long)gridDim.x * 64) {
+		const bool valid = base + lane < cnt;
+		const long long pos = cnt - 1 - (valid ? base + lane : base); // sorted ascending by rows: longest first
+		const uint32_t idx = order ? order[pos] : (uint32_t)pos;
+		const uint4 *tp = (const uint4 *)(tasks + idx);
+		const uint4 ta = tp[0], tb = tp[1];
+		const uint64_t q_off = (uint64_t)ta.y << 32 | ta.x, t_off = (uint64_t)ta.w << 32 | ta.z;
+		const int qlen = (int)(tb.x & 0xffff), tlen = (int)(tb.x >> 16);
+		const int w = (int)tb.y;
+		const uint32_t cigar_off = tb.z;
+		const int cigar_cap = (int)tb.w;
+		const bool want = cigar_cap > 0;
+		const bool bad = w < 0 || 2 * w + 2 > C || tlen > rows_cap;
+		if (valid && bad) {
+			out[idx].score = INT32_MIN, out[idx].n_cigar = 0;
+			atomicExch(err_flag, BMH_E_RANGE);
+		}
+		const bool live = valid && !bad;
+
+		// ---- row state before row 0 (ksw.c:519-522): slot s is column s-w
+		int R[C + 1], QW[NQ];
+#pragma unroll
+		for (int s = 0; s <= C; ++s) {
+			const int j = s - w;
+			const int hd = j < 0 ? kNeg16 : (j == 0 ? 0 : (j <= w && j <= qlen ? -(P.o_ins + e_ins * j) : kNeg16));
+			R[s] = (int)((uint32_t)kNeg16 << 16 | ((uint32_t)hd & 0xffffu)); // {H(-1,j-1) as eh[j].h, E = -inf}
+		}
+#pragma unroll
+		for (int v = 0; v < NQ; ++v) {
+			int sv = 0;
+#pragma unroll
+			for (int b = 0; b < 4; ++b) {
+				const int j = 4 * v + b - w;
+				int qb = 4;
+				if (live && j >= 0 && j < qlen) qb = pool[q_off + (uint64_t)j];
+				sv |= qb << (8 * b);
+			}
+			QW[v] = sv;
+		}
+		int tnext = 0, qnext = 4;
+		if (live && tlen > 0) tnext = pool[t_off];
+		{
+			const int j = 1 - w + C - 1; // the byte that enters slot C-1 at row 1
+			if (live && j >= 0 && j < qlen) qnext = pool[q_off + (uint64_t)j];
+		}
+		int i = 0, score = kNeg16;
+		for (; __builtin_amdgcn_ballot_w64(live && i < tlen) != 0; ++i) { // ksw.c:524-564; i is wave-uniform
+			const bool rowon = live && i < tlen;
+			const int tcur = tnext, qin = qnext;
+			tnext = 0, qnext = 4;
+			if (live && i + 1 < tlen) tnext = pool[t_off + (uint64_t)(i + 1)];
+			{
+				const int j = i + 2 - w + C - 1;
+				if (live && i + 2 < tlen && j >= 0 && j < qlen) qnext = pool[q_off + (uint64_t)j];
+			}
+			const uint2 row = srow[min(tcur, 4)];
+			const int slo = rowon ? max(0, w - i) : C + 1;
+			const int shi = rowon ? min(2 * w + 1, qlen - i + w) : C + 1;
+			int am[NW];
+#pragma unroll
+			for (int v = 0; v < NW; ++v) {
+				const int lo = min(max(slo - 32 * v, 0), 32), hi = min(max(shi - 32 * v, 0), 32);
+				am[v] = hi > lo ? (int)((0xffffffffu >> (32 - (hi - lo))) << lo) : 0;
+			}
+			const int fill = i < w ? -(P.o_del + e_del * (i + 1)) : kNeg16; // ksw.c:530: first-column value while beg == 0
+			int f = kNeg16;
+			uint32_t *zrow = zw + (size_t)i * (size_t)(NQ * 64);
+#pragma unroll
+			for (int b = 0; b < NB; ++b) {
+				// needed iff the block meets [slo-1, shi): slot slo-1 is the virtual column -1 that must receive `fill`
+				if (__builtin_amdgcn_ballot_w64(slo <= 8 * b + 8 && shi > 8 * b) == 0) continue;
+				uint32_t dz = 0;
+#pragma unroll
+				for (int c = 0; c < 8; ++c) {
+					const int s = 8 * b + c;
+					const int actv = (am[s / 32] << (31 - s % 32)) >> 31;
+					const unsigned sel = __builtin_amdgcn_perm((unsigned)QW[s / 4], row.y, 0x0c0c0c04u + (unsigned)(s % 4));
+					const int sc = (int)(int8_t)__builtin_amdgcn_perm(row.y, row.x, sel);
+					const int m = (int)(int16_t)(R[s] & 0xffff) + sc; // M(i,j) = H(i-1,j-1) + S, ksw.c:546
+					const int e = R[s + 1] >> 16;                      // E(i,j)
+					int d = m >= e ? 0 : 1;                            // ksw.c:547-550
+					int h = max(m, e);
+					d = h >= f ? d : 2;
+					h = max(h, f);
+					const int t1 = m - oe_del, e2 = e - e_del;         // ksw.c:552-556
+					d |= e2 > t1 ? 1 << 2 : 0;
+					const int en = max(e2, t1);
+					const int t2 = m - oe_ins, f2 = f - e_ins;         // ksw.c:557-560
+					d |= f2 > t2 ? 2 << 4 : 0;
+					f = sel3(actv, max(f2, t2), kNeg16);
+					// register s <- {H(i,j) for the next row's diagonal, E(i+1,j) for the next row's slot s-1}
+					R[s] = (int)__builtin_amdgcn_perm((unsigned)sel3(actv, en, kNeg16), (unsigned)sel3(actv, h, fill), 0x05040100u);
+					dz |= (uint32_t)d << (8 * (c & 3));
+					if ((c & 3) == 3) {
+						if (want) zrow[(size_t)(s / 4) * 64] = dz; // ksw.c:561
+						dz = 0;
+					}
+				}
+			}
+			// score = eh[qlen].h after the LAST row of a lane = H(tlen-1, qlen-1), ksw.c:565: slot qlen-tlen+w of that row.
+			// Picked up right here because the registers of a finished lane are refilled by the rows other lanes still run.
+			if (__builtin_amdgcn_ballot_w64(live && i == tlen - 1)) {
+				const int ss = qlen - tlen + w;
+#pragma unroll
+				for (int s = 0; s < C; ++s)
+					if (live && i == tlen - 1 && s == ss) score = (int)(int16_t)(R[s] & 0xffff);
+			}
+			// slide the query window by one base (row i+1 looks at q[i+1-w+s])
+#pragma unroll
+			for (int v = 0; v + 1 < NQ; ++v) QW[v] = (int)__builtin_amdgcn_alignbyte((unsigned)QW[v + 1], (unsigned)QW[v], 1u);
+			QW[NQ - 1] = (int)__builtin_amdgcn_alignbyte((unsigned)qin, (unsigned)QW[NQ - 1], 1u);
+		}
+
+		if (tlen == 0) score = qlen == 0 ? 0 : (qlen <= w ? -(P.o_ins + e_ins * qlen) : kNeg16); // eh[qlen].h of ksw.c:519-522
+		if (score <= kNeg16 / 2) score = -0x40000000; // the reference's MINUS_INF (out-of-domain input only)
+
+		// ---- traceback, ksw.c:566-581, one path per lane
+		int n_cigar = 0;
+		if (__builtin_amdgcn_ballot_w64(live && want)) {
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); // direction words of this wave are in flight
+			uint32_t *cg = cigar_pool + cigar_off;
+			int ti = tlen - 1, tk = min(qlen, tlen - 1 + w + 1) - 1, which = 0, last_op = 0, last_len = 0, nw = 0;
+			bool on = live && want;
+			while (__builtin_amdgcn_ballot_w64(on && ti >= 0 && tk >= 0)) {
+				if (on && ti >= 0 && tk >= 0) {
+					const int s = min(max(tk - (ti - w), 0), C - 1);
+					const uint32_t dzw = zw[((size_t)ti * NQ + (size_t)(s >> 2)) * 64];
+					which = (int)(dzw >> (8 * (s & 3)) >> (which << 1)) & 3;
+					const int op = which == 0 ? 0 : (which == 1 ? 2 : 1);
+					if (last_len > 0 && op == last_op) ++last_len; // ksw.c:489-499
+					else {
+						if (last_len > 0) {
+							if (nw < cigar_cap) cg[cigar_cap - 1 - nw] = (uint32_t)last_len << 4 | (uint32_t)last_op;
+							++nw;
+						}
+						last_op = op, last_len = 1;
+					}
+					ti -= which != 2;
+					tk -= which != 1;
+				}
+			}
+			if (on) {
+				for (int pass = 0; pass < 2; ++pass) { // leftovers, ksw.c:576-577: deletions then insertions
+					const int op = pass == 0 ? 2 : 1, len = pass == 0 ? ti + 1 : tk + 1;
+					if (len <= 0) continue;
+					if (last_len > 0 && op == last_op) last_len += len;
+					else {
+						if (last_len > 0) {
+							if (nw < cigar_cap) cg[cigar_cap - 1 - nw] = (uint32_t)last_len << 4 | (uint32_t)last_op;
+							++nw;
+						}
+						last_op = op, last_len = len;
+					}
+				}
+				if (last_len > 0) {
+					if (nw < cigar_cap) cg[cigar_cap - 1 - nw] = (uint32_t)last_len << 4 | (uint32_t)last_op;
+					++nw;
+				}
+				n_cigar = nw;
+				// the words sit at [cap-n, cap) in forward order; move them to [0, n)
+				const int shift = cigar_cap - nw;
+				if (shift > 0 && nw <= cigar_cap) {
+					__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+					for (int c = 0; c < nw; ++c) cg[c] = cg[shift + c];
+				}
+				if (nw > cigar_cap) atomicExch(err_flag, BMH_E_CIGAR_CAP);
+			}
+		}
+		if (live) out[idx].score = score, out[idx].n_cigar = n_cigar;
+	}
+}
+
+// ---- launcher: tasks listed in d_order[0..*d_count) must have 2w+2 <= C and tlen <= rows_cap
+int launch_global_lane(bmh_ctx *ctx, int c, const uint8_t *d_pool, const bmh_glb_task_t *d_tasks, int64_t n,
+                       bmh_glb_result_t *d_res, uint32_t *d_cigar, const uint32_t *d_order, const uint32_t *d_count,
+                       int rows_cap)
+{
+	if (n <= 0) return BMH_OK;
+	int ncu = 256;
+	(void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
+	long long grid = (n + 63) / 64;
+	const long long resident = (long long)ncu * 4 * (c <= 64 ? 3 : 2) * 2; // persistent: ~2x the resident waves
+	if (grid > resident) grid = resident;
+	const size_t slab = (size_t)grid * (size_t)rows_cap * (size_t)(c / 4) * 64 * 4;
+	int rc = ensure(ctx, ctx->d_zslab, slab);
+	if (rc) return rc;
+#define BMH_LAUNCH_GL(CC)                                                                                             \
+	hipLaunchKernelGGL(global_lane_kernel<CC>, dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_pool, d_tasks, d_order, \
+	                   d_count, (long long)n, d_res, d_cigar, ctx->dev, (uint32_t *)ctx->d_zslab.p, rows_cap, ctx->d_err)
+	if (c == 64) BMH_LAUNCH_GL(64);
+	else if (c == 128) BMH_LAUNCH_GL(128);
+	else return BMH_E_ARG;
+#undef BMH_LAUNCH_GL
+	BMH_HIP(ctx, hipGetLastError());
+	return BMH_OK;
+}
+
+} // namespace bmh

@@ -157,3 +157,46 @@ int64_t bmh_taskgen_ext(const bmh_taskgen_cfg_t *cfg, const bmh_params_t *p, int
 	if (pool_used) *pool_used = used;
 	return nt;
 }
+
+/* Global-alignment tasks as bwa_gen_cigar2 hands them to ksw_global2 (reference bwa.c:116-132): the whole read
+ * against the window it came from, band = |tlen-qlen| + 3 .. +3+wspread (measured mean 19).
+ * Returns the number of tasks (one per read) or -1 if a capacity is too small. */
+int64_t bmh_taskgen_glb(const bmh_taskgen_cfg_t *cfg, int64_t n_reads, int wspread, uint8_t *pool, size_t pool_cap,
+                        size_t *pool_used, bmh_glb_task_t *tasks, int64_t task_cap, uint64_t *cigar_words)
+{
+	const int Lmax = cfg->len_max;
+	uint8_t *ref = (uint8_t *)malloc((size_t)Lmax * 2 + 64), *rd = (uint8_t *)malloc((size_t)Lmax + 64);
+	int64_t nt = 0, r;
+	size_t used = 0;
+	uint64_t s = cfg->seed, cw = 0;
+	for (r = 0; r < n_reads; ++r) {
+		const int L = irand(&s, cfg->len_min, cfg->len_max);
+		int i, x, n = 0;
+		for (i = 0; i < 2 * Lmax + 32; ++i) ref[i] = (uint8_t)(splitmix(&s) & 3);
+		for (x = 0; n < L && x < 2 * Lmax;) {
+			const double u = urand(&s);
+			if (u < cfg->p_sub) rd[n++] = (uint8_t)((ref[x++] + 1 + splitmix(&s) % 3) & 3);
+			else if (u < cfg->p_sub + cfg->p_ins) {
+				int k = irand(&s, 1, cfg->max_indel);
+				for (; k > 0 && n < L; --k) rd[n++] = (uint8_t)(splitmix(&s) & 3);
+			} else if (u < cfg->p_sub + cfg->p_ins + cfg->p_del) x += irand(&s, 1, cfg->max_indel);
+			else rd[n++] = ref[x++];
+		}
+		if (n < L || x < 1) continue;
+		if (used + (size_t)L + (size_t)x + 16 > pool_cap || nt + 1 > task_cap) { nt = -1; break; }
+		{
+			bmh_glb_task_t *t = &tasks[nt++];
+			memcpy(pool + used, rd, (size_t)L);
+			memcpy(pool + used + L, ref, (size_t)x);
+			t->q_off = used, t->t_off = used + (uint64_t)L, t->qlen = (uint16_t)L, t->tlen = (uint16_t)x;
+			t->w = abs(x - L) + 3 + irand(&s, 0, wspread);
+			t->cigar_off = (uint32_t)cw, t->cigar_cap = (uint32_t)(L + x + 2);
+			cw += t->cigar_cap;
+			used += (size_t)L + (size_t)x;
+		}
+	}
+	free(ref), free(rd);
+	if (pool_used) *pool_used = used;
+	if (cigar_words) *cigar_words = cw;
+	return nt;
+}

@@ -34,6 +34,7 @@ def _load():
         L = C.CDLL(TASKGEN_PATH)
         L.bmh_taskgen_ext.restype = C.c_int64
         L.bmh_taskgen_pool_bound.restype = C.c_size_t
+        L.bmh_taskgen_glb.restype = C.c_int64
         _lib = L
     return _lib
 
@@ -57,3 +58,21 @@ def generate(params, n_reads, workload="150bp", seed=7, ext_task_dtype=None):
     pool = pool[: used.value + 16]
     pool[used.value:] = 0
     return pool, tasks[:nt].copy(), tread[:nt].copy()
+
+
+def generate_global(n_reads, workload="150bp", seed=11, wspread=32):
+    """Returns (pool, tasks GLB_TASK[], cigar_words) -- one banded global alignment per simulated read."""
+    from . import GLB_TASK
+    L = _load()
+    cfg = Cfg(seed=seed, **WORKLOADS[workload])
+    pool = np.empty(int(n_reads) * (cfg.len_max * 3 + 64) + 64, dtype=np.uint8)
+    tasks = np.zeros(int(n_reads) + 1, dtype=GLB_TASK)
+    used, cw = C.c_size_t(0), C.c_uint64(0)
+    nt = L.bmh_taskgen_glb(C.byref(cfg), C.c_int64(n_reads), C.c_int(wspread), pool.ctypes.data_as(C.c_void_p),
+                           C.c_size_t(pool.nbytes), C.byref(used), tasks.ctypes.data_as(C.c_void_p),
+                           C.c_int64(len(tasks)), C.byref(cw))
+    if nt < 0:
+        raise RuntimeError("taskgen capacity too small")
+    pool = pool[: used.value + 16]
+    pool[used.value:] = 0
+    return pool, tasks[:nt].copy(), int(cw.value)

@@ -275,3 +275,56 @@ int orc_extend_batch(const orc_scoring_t *sc, const uint8_t *seqpool,
 	if (cells_out) *cells_out = cells;
 	return 0;
 }
+
+/* ------------------------------------------------------- global batch helper */
+
+typedef struct {
+	const orc_scoring_t *sc;
+	const uint8_t *pool;
+	const bmh_glb_task_t *tasks;
+	bmh_glb_result_t *res;
+	uint32_t *cigar_pool;
+	int lo, hi;
+	int64_t cells;
+} glb_job_t;
+
+static void *glb_job_run(void *p)
+{
+	glb_job_t *job = (glb_job_t *)p;
+	int k;
+	for (k = job->lo; k < job->hi; ++k) {
+		const bmh_glb_task_t *tk = &job->tasks[k];
+		int n = 0, i, w = tk->w, ncol = tk->qlen < 2 * w + 1 ? tk->qlen : 2 * w + 1;
+		uint32_t *cg = 0;
+		job->res[k].score = orc_global(job->sc, tk->qlen, job->pool + tk->q_off, tk->tlen, job->pool + tk->t_off, w,
+		                               tk->cigar_cap ? &n : 0, tk->cigar_cap ? &cg : 0);
+		job->res[k].n_cigar = n;
+		for (i = 0; i < n && i < (int)tk->cigar_cap; ++i) job->cigar_pool[tk->cigar_off + i] = cg[i];
+		free(cg);
+		job->cells += (int64_t)ncol * tk->tlen; /* band cells, ksw.c:528-529 upper bound */
+	}
+	return 0;
+}
+
+int orc_global_batch(const orc_scoring_t *sc, const uint8_t *seqpool, const struct bmh_glb_task *tasks, int n,
+                     struct bmh_glb_result *results, uint32_t *cigar_pool, int64_t *cells_out, int nthreads)
+{
+	int i;
+	int64_t cells = 0;
+	glb_job_t jobs[256];
+	pthread_t tid[256];
+	if (nthreads < 1) nthreads = 1;
+	if (nthreads > 256) nthreads = 256;
+	for (i = 0; i < nthreads; ++i) {
+		jobs[i].sc = sc, jobs[i].pool = seqpool, jobs[i].tasks = tasks, jobs[i].res = results, jobs[i].cigar_pool = cigar_pool;
+		jobs[i].lo = (int)((int64_t)n * i / nthreads), jobs[i].hi = (int)((int64_t)n * (i + 1) / nthreads), jobs[i].cells = 0;
+	}
+	if (nthreads == 1) glb_job_run(&jobs[0]);
+	else {
+		for (i = 0; i < nthreads; ++i) pthread_create(&tid[i], 0, glb_job_run, &jobs[i]);
+		for (i = 0; i < nthreads; ++i) pthread_join(tid[i], 0);
+	}
+	for (i = 0; i < nthreads; ++i) cells += jobs[i].cells;
+	if (cells_out) *cells_out = cells;
+	return 0;
+}

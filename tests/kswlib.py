@@ -335,3 +335,19 @@ def golden_cigar_groups():
         sel = np.nonzero(g["group"] == k)[0]
         exp = [(int(g["exp_n_cigar"][i]), g["exp_cigar"][woff[i]:woff[i + 1]], int(g["exp_nm"][i]), mds[i]) for i in sel]
         yield g["params"][k], l_pac, pac, reads, g["reqs"][sel], exp
+
+
+def orc_global_batch_mt(p, pool, tasks, cigar_words, nthreads=1):
+    """Threaded oracle run of N x ksw_global2 (for the CPU baseline): (results, cigar_pool, band_cells)."""
+    lib = load_oracle()
+    keep = []
+    sc = scoring_of(p, keep)
+    tasks = np.ascontiguousarray(tasks)
+    pool = np.ascontiguousarray(pool)
+    res = np.zeros(len(tasks), dtype=GLB_RES)
+    cig = np.zeros(max(int(cigar_words), 1), dtype=np.uint32)
+    cells = C.c_int64(0)
+    lib.orc_global_batch(C.byref(sc), pool.ctypes.data_as(C.c_void_p), tasks.ctypes.data_as(C.c_void_p),
+                         C.c_int(len(tasks)), res.ctypes.data_as(C.c_void_p), cig.ctypes.data_as(C.c_void_p),
+                         C.byref(cells), C.c_int(nthreads))
+    return res, cig, cells.value
