@@ -146,7 +146,7 @@ def main():
                             * gtasks["tlen"].astype(np.int64)).sum())
         g_bytes = float(gtasks["qlen"].astype(np.int64).sum() + gtasks["tlen"].astype(np.int64).sum()
                         + 40 * len(gtasks) + 4 * gres["n_cigar"].astype(np.int64).sum())
-        glb = {"kernel": "global_kernel (ksw_global2 + traceback)", "tasks": int(len(gtasks)), "ms": g_ms,
+        glb = {"kernel": "global_lane_kernel<64|128> (ksw_global2 + traceback, 64 tasks/wave)", "tasks": int(len(gtasks)), "ms": g_ms,
                "tasks_per_s": len(gtasks) / (g_ms * 1e-3), "band_gcups": band_cells / (g_ms * 1e-3) / 1e9,
                "algorithmic_GBps": g_bytes / (g_ms * 1e-3) / 1e9, "mean_w": float(gtasks["w"].mean()),
                "parity": "bit-exact vs oracle (scores, n_cigar, sampled CIGARs)" if ok else "MISMATCH vs oracle",

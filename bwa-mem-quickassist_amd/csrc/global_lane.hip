@@ -27,8 +27,14 @@ constexpr int kNeg16 = -16384;
 
 __device__ __forceinline__ int sel3(int mask, int a, int b) { return __builtin_amdgcn_bitop3_b32(mask, a, b, 0xca); }
 
+#ifndef BMH_GL_WAVES64
+#define BMH_GL_WAVES64 2 /* measured: (2,1) 3.08 ms, (3,1) 3.21 ms, (3,2) 3.67 ms per 250k tasks */
+#endif
+#ifndef BMH_GL_WAVES128
+#define BMH_GL_WAVES128 1
+#endif
 template <int C>
-__global__ __launch_bounds__(64, (C <= 64 ? 3 : 2)) void global_lane_kernel(
+__global__ __launch_bounds__(64, (C <= 64 ? BMH_GL_WAVES64 : BMH_GL_WAVES128)) void global_lane_kernel(
     const uint8_t *__restrict__ pool, const bmh_glb_task_t *__restrict__ tasks, const uint32_t *__restrict__ order,
     const uint32_t *__restrict__ count, long long n, bmh_glb_result_t *__restrict__ out, uint32_t *__restrict__ cigar_pool,
     DevParams P, uint32_t *__restrict__ zslab, int rows_cap, int *__restrict__ err_flag)
@@ -227,9 +233,10 @@ int launch_global_lane(bmh_ctx *ctx, int c, const uint8_t *d_pool, const bmh_glb
 	int ncu = 256;
 	(void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
 	long long grid = (n + 63) / 64;
-	const long long resident = (long long)ncu * 4 * (c <= 64 ? 3 : 2) * 2; // persistent: ~2x the resident waves
+	const long long resident = (long long)ncu * 4 * (c <= 64 ? BMH_GL_WAVES64 : BMH_GL_WAVES128) * 2; // persistent: ~2x the resident waves
 	if (grid > resident) grid = resident;
-	const size_t slab = (size_t)grid * (size_t)rows_cap * (size_t)(c / 4) * 64 * 4;
+	// one slab serves both lane kernels of a launch (they run back to back on the stream): size it for the larger one
+	const size_t slab = (size_t)ncu * 4 * 2 * 2 * (size_t)rows_cap * (size_t)(128 / 4) * 64 * 4;
 	int rc = ensure(ctx, ctx->d_zslab, slab);
 	if (rc) return rc;
 #define BMH_LAUNCH_GL(CC)                                                                                             \
