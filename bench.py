@@ -190,18 +190,20 @@ def main():
                "grp": ["extend_grp_kernel<2> (qlen<=32, 4 tasks/wave)", "extend_grp_kernel<4> (qlen<=64, 4 tasks/wave)",
                        "extend_grp_kernel<8> (qlen<=128, 4 tasks/wave)"],
                "reg": ["extend_reg_kernel<1> (qlen<=32)", "extend_reg_kernel<1> (qlen<=64)", "extend_reg_kernel<2> (qlen<=128)"],
-               "lds": ["-", "-", "-"]}[mode]
-        bin_names = fam + ["extend_reg_kernel<4> (qlen<=256)", "extend_lds_kernel (longer)"]
+               "lds": ["-", "-", "-"]}[mode if mode != "lanex4" else "lane"]
+        bin_names = fam + (["extend_lanex_kernel<2> (qlen<=256, 32 tasks/wave)", "extend_lanex_kernel<4> (qlen<=512, 16 tasks/wave)"]
+                           if mode in ("lane", "lanex4") else ["extend_reg_kernel<4> (qlen<=256)", "-"]) + ["extend_lds_kernel (longer)"]
         ql = tasks["qlen"].astype(np.int64)
         tl = tasks["tlen"].astype(np.int64)
-        which = np.where(ql < 1, 4, np.where(ql <= 32, 0, np.where(ql <= 64, 1, np.where(ql <= 128, 2, np.where(ql <= 256, 3, 4)))))
+        which = np.where(ql < 1, 5, np.where(ql <= 32, 0, np.where(ql <= 64, 1, np.where(ql <= 128, 2, np.where(
+            ql <= 256, 3, np.where((ql <= 512) & (mode == "lanex4"), 4, 5))))))
         if mode == "grp":
             which = np.where((ql >= 1) & (ql <= 256) & (tl > 1024), 3, which)
         if mode == "lds":
-            which[:] = 4
+            which[:] = 5
         per_task_bytes = ql + tasks["tlen"].astype(np.int64) + 56  # qlen + tlen + 32 + 24
         kernels = []
-        for b in range(5):
+        for b in range(6):
             nb = int((which == b).sum())
             if nb == 0:
                 continue

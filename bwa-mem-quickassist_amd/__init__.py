@@ -167,7 +167,7 @@ class Context:
         return ms.value
 
     def last_extend_bin_ms(self):
-        ms = (C.c_float * 5)()
+        ms = (C.c_float * 6)()
         self._check(lib().bmh_last_extend_bin_ms(self._h, ms))
         return [float(x) for x in ms]
 

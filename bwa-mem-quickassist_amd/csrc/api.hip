@@ -107,15 +107,18 @@ int bmh_ctx_create(bmh_ctx_t **out, int device)
 	    (e = hipMalloc((void **)&ctx->d_err, sizeof(int))) != hipSuccess || (e = hipMemset(ctx->d_err, 0, sizeof(int))) != hipSuccess ||
 	    (e = hipHostMalloc((void **)&ctx->h_err, sizeof(int), hipHostMallocDefault)) != hipSuccess ||
 	    (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess ||
-	    (e = hipEventCreate(&ctx->ev_bin[0])) != hipSuccess || (e = hipEventCreate(&ctx->ev_bin[1])) != hipSuccess ||
-	    (e = hipEventCreate(&ctx->ev_bin[2])) != hipSuccess || (e = hipEventCreate(&ctx->ev_bin[3])) != hipSuccess ||
-	    (e = hipEventCreate(&ctx->ev_bin[4])) != hipSuccess || (e = hipEventCreate(&ctx->ev_bin[5])) != hipSuccess) {
+	    false) {
 		fprintf(stderr, "[bwamem_hip] context creation failed: %s\n", hipGetErrorString(e));
 		bmh_ctx_destroy(ctx);
 		return BMH_E_NODEVICE;
 	}
+	for (int b = 0; b <= kExtBinsMax; ++b)
+		if (hipEventCreate(&ctx->ev_bin[b]) != hipSuccess) {
+			bmh_ctx_destroy(ctx);
+			return BMH_E_NODEVICE;
+		}
 	ctx->stream = ctx->own_stream;
-	if (const char *m = getenv("BMH_EXT_MODE")) ctx->force_kernel = !strcmp(m, "lds") ? 1 : !strcmp(m, "reg") ? 2 : !strcmp(m, "grp") ? 3 : 0;
+	if (const char *m = getenv("BMH_EXT_MODE")) ctx->force_kernel = !strcmp(m, "lds") ? 1 : !strcmp(m, "reg") ? 2 : !strcmp(m, "grp") ? 3 : !strcmp(m, "lanex4") ? 4 : 0;
 	if (const char *m = getenv("BMH_GLB_MODE")) ctx->glb_mode = !strcmp(m, "wave") ? 1 : 0;
 	if (const char *m = getenv("BMH_GRID_MULT")) ctx->grid_mult = atoi(m) > 0 ? atoi(m) : 1;
 	*out = ctx;
@@ -133,7 +136,7 @@ int bmh_ctx_destroy(bmh_ctx_t *ctx)
 	if (ctx->h_err) (void)hipHostFree(ctx->h_err);
 	if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
 	if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-	for (int b = 0; b < 6; ++b)
+	for (int b = 0; b <= kExtBinsMax; ++b)
 		if (ctx->ev_bin[b]) (void)hipEventDestroy(ctx->ev_bin[b]);
 	if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
 	delete ctx;
@@ -202,7 +205,7 @@ int bmh_last_kernel_ms(bmh_ctx_t *ctx, float *ms)
 	return BMH_OK;
 }
 
-int bmh_last_extend_bin_ms(bmh_ctx_t *ctx, float ms[5])
+int bmh_last_extend_bin_ms(bmh_ctx_t *ctx, float ms[6])
 {
 	if (!ctx || !ms) return BMH_E_ARG;
 	for (int b = 0; b < kExtBins; ++b) ms[b] = -1.f;

@@ -7,6 +7,8 @@
 #include "../../include/bwamem_hip.h"
 #include "bmh_device.h"
 
+constexpr int kExtBinsMax = 6;
+
 struct DevBuf { // grow-only device allocation
 	void *p = nullptr;
 	size_t cap = 0;
@@ -34,7 +36,7 @@ struct bmh_ctx {
 	bool timing = false;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	bool ev_valid = false;
-	hipEvent_t ev_bin[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; // boundaries of the extension bins
+	hipEvent_t ev_bin[kExtBinsMax + 1] = {}; // boundaries of the extension bins
 	bool ev_bin_valid = false;
 	std::string last_error;
 	bmh_driver_stats_t dstats{};
@@ -67,10 +69,12 @@ int sort_tasks_finish(bmh_ctx *ctx, int64_t n, const uint32_t *d_order, unsigned
 int launch_global_lane(bmh_ctx *ctx, int c, const uint8_t *d_pool, const bmh_glb_task_t *d_tasks, int64_t n,
                        bmh_glb_result_t *d_res, uint32_t *d_cigar, const uint32_t *d_order, const uint32_t *d_count,
                        int rows_cap);
-constexpr int kExtBins = 5;        // length bins of the extension dispatcher
+constexpr int kExtBins = 6;        // length bins of the extension dispatcher
 constexpr int kGrpTcapHost = 1024; // == kGrpTcap in extend_grp.hip
 int launch_extend_grp(bmh_ctx *ctx, int nv, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
                       bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count);
+int launch_extend_lanex(bmh_ctx *ctx, int lpt, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
+                        bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count);
 int launch_extend_lane(bmh_ctx *ctx, int c, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
                        bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count);
 int launch_extend_reg(bmh_ctx *ctx, int ns, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,

@@ -3,8 +3,10 @@
 //   bin 0: qlen <= 32    extend_lane_kernel<32>   (64 tasks per wave, one lane per task)
 //   bin 1: qlen <= 64    extend_lane_kernel<64>
 //   bin 2: qlen <= 128   extend_lane_kernel<128>
-//   bin 3: qlen <= 256   extend_reg_kernel<4>     (one task per wave, 4 columns per lane)
-//   bin 4: longer or qlen == 0                     extend_lds_kernel
+//   bin 3: qlen <= 256   extend_lanex_kernel<2>   (32 tasks per wave, two lanes x 128 columns per task)
+//   bin 4: qlen <= 512   extend_lanex_kernel<4>   (16 tasks per wave; only with BMH_EXT_MODE=lanex4: with the few
+//                        such tasks a 150-300 bp run produces, one wave per task keeps more of the chip busy)
+//   bin 5: longer or qlen == 0                     extend_lds_kernel  (one wave per task)
 // BMH_EXT_MODE=reg | grp | lds in the environment selects the one-task-per-wave register kernels, the
 // four-tasks-per-wave group kernels, or the LDS kernel for bins 0-2 instead (A/B runs, profiles/).
 //
@@ -22,10 +24,11 @@ constexpr int kSortKeys = 2048;
 
 __device__ __forceinline__ int ext_bin_of(int qlen, int tlen, int mode)
 {
-	// mode 0: lane-per-task kernels for qlen <= 128; 1: LDS kernel only; 2: one task per wave; 3: four tasks per wave
-	if (mode == 1 || qlen < 1) return 4;
+	// mode 0: lane-per-task kernels (qlen <= 256); 1: LDS kernel only; 2: one task per wave; 3: four tasks per wave;
+	// 4: like 0 plus the four-lanes-per-task kernel for qlen <= 512
+	if (mode == 1 || qlen < 1) return 5;
 	if (mode == 3 && qlen <= 256 && tlen > kGrpTcapHost) return 3; // the group kernels stage the target in LDS
-	return qlen <= 32 ? 0 : qlen <= 64 ? 1 : qlen <= 128 ? 2 : qlen <= 256 ? 3 : 4;
+	return qlen <= 32 ? 0 : qlen <= 64 ? 1 : qlen <= 128 ? 2 : qlen <= 256 ? 3 : (qlen <= 512 && mode == 4) ? 4 : 5;
 }
 
 // sort key inside a bin: query-length bucket (major; lanes of a wave then share the unused leading columns,
@@ -33,9 +36,9 @@ __device__ __forceinline__ int ext_bin_of(int qlen, int tlen, int mode)
 // rows run at most to tlen, and the band leaves the query after ~qlen+w <= 2*qlen rows (ksw.c:418).
 __device__ __forceinline__ int ext_sort_key(int bin, int qlen, int tlen, int h0)
 {
-	if (bin > 2) return 0;
-	const int qlo = bin == 0 ? 1 : (16 << bin) + 1, qsh = bin == 2 ? 2 : 1; // 16 query-length buckets per bin
-	const int rows = min(tlen, 2 * qlen + 8);
+	if (bin > 4) return 0;
+	const int qlo = bin == 0 ? 1 : (16 << bin) + 1, qsh = bin < 2 ? 1 : bin; // 16 query-length buckets per bin
+	const int rows = min(tlen, 2 * qlen + 8) >> (bin > 2 ? bin - 2 : 0);
 	// h0 decides how wide the live interval is (cells stay non-zero within ~h0-o-e of the diagonal), so lanes
 	// with a similar h0 need the same 8-column blocks
 	return (((qlen - qlo) >> qsh) * 8 + min(max(h0, 0) >> 4, 7)) * 16 + min(rows >> 4, 15);
@@ -160,14 +163,17 @@ int launch_extend(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_t
 	for (int b = 0; b < kExtBins; ++b) {
 		if (tm) BMH_HIP(ctx, hipEventRecord(ctx->ev_bin[b], ctx->stream));
 		const uint32_t *lst = lists + (size_t)b * N, *cnt = counts + b;
-		const int qlo = b == 0 ? 0 : 16 << b; // bins 0..3 hold qlen <= 32,64,128,256
-		if (b < 4 && (mode == 1 || qmax <= qlo)) continue; // provably empty bin
+		const int qlo = b == 0 ? 0 : 16 << b; // bins 0..4 hold qlen <= 32,64,128,256,512
+		if (b < 5 && (mode == 1 || qmax <= qlo)) continue; // provably empty bin
 		rc = BMH_OK;
 		if (b <= 2) {
-			if (mode == 0) rc = launch_extend_lane(ctx, 32 << b, d_pool, d_tasks, n, d_res, lst, cnt);
+			if (mode == 0 || mode == 4) rc = launch_extend_lane(ctx, 32 << b, d_pool, d_tasks, n, d_res, lst, cnt);
 			else if (mode == 3) rc = launch_extend_grp(ctx, 2 << b, d_pool, d_tasks, n, d_res, lst, cnt);
 			else rc = launch_extend_reg(ctx, b == 2 ? 2 : 1, d_pool, d_tasks, n, d_res, lst, cnt);
-		} else if (b == 3) rc = launch_extend_reg(ctx, 4, d_pool, d_tasks, n, d_res, lst, cnt);
+		} else if (b == 3) {
+			rc = (mode == 0 || mode == 4) ? launch_extend_lanex(ctx, 2, d_pool, d_tasks, n, d_res, lst, cnt)
+			               : launch_extend_reg(ctx, 4, d_pool, d_tasks, n, d_res, lst, cnt);
+		} else if (b == 4 && mode == 4) rc = launch_extend_lanex(ctx, 4, d_pool, d_tasks, n, d_res, lst, cnt);
 		else rc = launch_extend_lds(ctx, d_pool, d_tasks, mode != 1 && qmax <= 256 ? 4096 : n, d_res, lst, cnt, qmax);
 		if (rc) return rc;
 	}

@@ -155,8 +155,8 @@ int bmh_extend_batch_sharded(bmh_ctx_t *const *ctxs, int n_ctx, const uint8_t *s
 int bmh_last_kernel_ms(bmh_ctx_t *ctx, float *ms);
 int bmh_set_kernel_timing(bmh_ctx_t *ctx, int enable);
 /* Per-kernel duration of the last extension launch, one entry per query-length bin of the dispatcher:
- * qlen <= 32, <= 64, <= 128, <= 256, longer (LDS kernel).  -1 when timing was off. */
-int bmh_last_extend_bin_ms(bmh_ctx_t *ctx, float ms[5]);
+ * qlen <= 32, <= 64, <= 128, <= 256, <= 512, longer (LDS kernel).  -1 when timing was off. */
+int bmh_last_extend_bin_ms(bmh_ctx_t *ctx, float ms[6]);
 
 /* ---- L3: data carriers of the extension driver, layout-compatible with the
  * reference so that its structs can be passed straight through. */
