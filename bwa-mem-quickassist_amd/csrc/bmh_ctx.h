@@ -74,11 +74,11 @@ constexpr int kGrpTcapHost = 1024; // == kGrpTcap in extend_grp.hip
 int launch_extend_grp(bmh_ctx *ctx, int nv, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
                       bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count);
 int launch_extend_lanex(bmh_ctx *ctx, int lpt, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
-                        bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count);
+                        bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, int min_count);
 int launch_extend_lane(bmh_ctx *ctx, int c, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
                        bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count);
 int launch_extend_reg(bmh_ctx *ctx, int ns, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
-                      bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count);
+                      bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, int max_count = 0);
 int launch_global(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_glb_task_t *d_tasks, int64_t n,
                   bmh_glb_result_t *d_res, uint32_t *d_cigar, const uint32_t *d_order, int qmax, int tmax,
                   int wmax);

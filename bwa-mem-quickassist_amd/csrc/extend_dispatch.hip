@@ -45,6 +45,7 @@ __device__ __forceinline__ int ext_sort_key(int bin, int qlen, int tlen, int h0)
 }
 
 constexpr int kSortBlocks = 512, kSortThreads = 256;
+constexpr int kLanexMinTasks = 4096; // below this many 129-256 bp flanks one wave per task fills the chip better
 
 // pass 1: per-block histogram in LDS over a contiguous chunk, flushed with one global atomic per used key
 __global__ __launch_bounds__(kSortThreads) void sort_hist_kernel(const bmh_ext_task_t *__restrict__ tasks,
@@ -171,9 +172,11 @@ int launch_extend(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_t
 			else if (mode == 3) rc = launch_extend_grp(ctx, 2 << b, d_pool, d_tasks, n, d_res, lst, cnt);
 			else rc = launch_extend_reg(ctx, b == 2 ? 2 : 1, d_pool, d_tasks, n, d_res, lst, cnt);
 		} else if (b == 3) {
-			rc = (mode == 0 || mode == 4) ? launch_extend_lanex(ctx, 2, d_pool, d_tasks, n, d_res, lst, cnt)
-			               : launch_extend_reg(ctx, 4, d_pool, d_tasks, n, d_res, lst, cnt);
-		} else if (b == 4 && mode == 4) rc = launch_extend_lanex(ctx, 4, d_pool, d_tasks, n, d_res, lst, cnt);
+			if (mode == 0 || mode == 4) { // both are launched; the bin size (known on the device only) decides which one works
+				rc = launch_extend_lanex(ctx, 2, d_pool, d_tasks, n, d_res, lst, cnt, kLanexMinTasks);
+				if (!rc) rc = launch_extend_reg(ctx, 4, d_pool, d_tasks, n < kLanexMinTasks ? n : kLanexMinTasks, d_res, lst, cnt, kLanexMinTasks);
+			} else rc = launch_extend_reg(ctx, 4, d_pool, d_tasks, n, d_res, lst, cnt);
+		} else if (b == 4 && mode == 4) rc = launch_extend_lanex(ctx, 4, d_pool, d_tasks, n, d_res, lst, cnt, 0);
 		else rc = launch_extend_lds(ctx, d_pool, d_tasks, mode != 1 && qmax <= 256 ? 4096 : n, d_res, lst, cnt, qmax);
 		if (rc) return rc;
 	}

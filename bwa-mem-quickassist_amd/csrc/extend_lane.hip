@@ -49,6 +49,9 @@ __global__ __launch_bounds__(64, BMH_LANE_WAVES(C)) void extend_lane_kernel(cons
 	constexpr int NW = C / 32, NQ = C / 4, NB = C / 8;
 	constexpr int INF = 0x7fff;
 	__shared__ uint2 srow[8]; // srow[t] = the 5 signed score bytes mat[t*5 .. t*5+4]
+#ifdef BMH_LANE_LDS_SEL
+	__shared__ uint8_t qsel[C * 64]; // query code of column p of lane l at [p*64+l]: one conflict-free ds_read_u8 per cell
+#endif
 	const int lane = threadIdx.x;
 	const int oe_del = P.o_del + P.e_del, oe_ins = P.o_ins + P.e_ins;
 	const int e_del = P.e_del, e_ins = P.e_ins;
@@ -84,7 +87,16 @@ __global__ __launch_bounds__(64, BMH_LANE_WAVES(C)) void extend_lane_kernel(cons
 	const int off = C - min(max(qlen, 1), C);
 
 	// ---- per-lane column state (ksw.c:389-396), query right-aligned
-	int HE[C], QS[NQ];
+	int HE[C];
+#ifdef BMH_LANE_LDS_SEL
+	for (int p = 0; p < C; ++p) {
+		const int j = p - off;
+		int qb = 4;
+		if (valid && !bad && j >= 0) qb = seq_base(pool, q_off, j, qrev);
+		qsel[p * 64 + lane] = (uint8_t)qb;
+	}
+#else
+	int QS[NQ];
 #pragma unroll
 	for (int v = 0; v < NQ; ++v) {
 		int s = 0;
@@ -97,6 +109,7 @@ __global__ __launch_bounds__(64, BMH_LANE_WAVES(C)) void extend_lane_kernel(cons
 		}
 		QS[v] = s;
 	}
+#endif
 #pragma unroll
 	for (int p = 0; p < C; ++p) {
 		const int j = p - off;
@@ -141,10 +154,14 @@ __global__ __launch_bounds__(64, BMH_LANE_WAVES(C)) void extend_lane_kernel(cons
 			for (int c = 0; c < 8; ++c) {
 				const int p = 8 * b + c;
 				const int actv = (am[p / 32] << (31 - p % 32)) >> 31;
+#ifdef BMH_LANE_LDS_SEL
+				const unsigned sel = qsel[p * 64 + lane];
+#else
 				// selector = query code of column p in byte 0.  The second operand is never selected; passing a
 				// row-variant value for C >= HOIST_LIMIT keeps hipcc from hoisting C selectors into C more VGPRs.
 				const unsigned sel = __builtin_amdgcn_perm((unsigned)QS[p / 4], C >= kLaneHoistLimit ? row.y : 0u,
 				                                           0x0c0c0c04u + (unsigned)(p % 4));
+#endif
 				const int sc = (int)(int8_t)__builtin_amdgcn_perm(row.y, row.x, sel);
 				const int e = (int)((unsigned)HE[p] >> 16);
 				const int hh = max((int)(HE[p] & 0xffff) + sc, e);          // ksw.c:430-431

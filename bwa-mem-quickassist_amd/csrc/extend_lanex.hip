@@ -43,7 +43,7 @@ __global__ __launch_bounds__(64, 2) void extend_lanex_kernel(const uint8_t *__re
                                                              const uint32_t *__restrict__ order,
                                                              const uint32_t *__restrict__ count, long long n,
                                                              bmh_ext_result_t *__restrict__ out, DevParams P,
-                                                             int *__restrict__ err_flag)
+                                                             int *__restrict__ err_flag, int min_count)
 {
 	constexpr int C = 128, TOT = C * LPT, TPW = 64 / LPT;
 	constexpr int NW = C / 32, NB = C / 8;
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(64, 2) void extend_lanex_kernel(const uint8_t *__re
 	}
 	const long long cnt = count ? (long long)*count : n;
 	const long long base = (long long)blockIdx.x * TPW;
-	if (base >= cnt) return;
+	if (base >= cnt || cnt < min_count) return; // a handful of tasks is served better by one wave per task (extend_reg_kernel)
 	const bool valid = base + lane / LPT < cnt;
 	const long long pos = cnt - 1 - (valid ? base + lane / LPT : base); // sorted ascending: expensive waves first
 	const uint32_t idx = order ? order[pos] : (uint32_t)pos;
@@ -217,17 +217,17 @@ __global__ __launch_bounds__(64, 2) void extend_lanex_kernel(const uint8_t *__re
 
 // ---- launcher: tasks listed in d_order[0..*d_count) must have 1 <= qlen <= 128*lpt
 int launch_extend_lanex(bmh_ctx *ctx, int lpt, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
-                        bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count)
+                        bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, int min_count)
 {
 	if (n <= 0) return BMH_OK;
 	const int tpw = 64 / lpt;
 	const long long grid = (n + tpw - 1) / tpw; // blocks past the bin's device-side count return at once
 	if (lpt == 2)
 		hipLaunchKernelGGL(extend_lanex_kernel<2>, dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_pool, d_tasks, d_order, d_count,
-		                   (long long)n, d_res, ctx->dev, ctx->d_err);
+		                   (long long)n, d_res, ctx->dev, ctx->d_err, min_count);
 	else if (lpt == 4)
 		hipLaunchKernelGGL(extend_lanex_kernel<4>, dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_pool, d_tasks, d_order, d_count,
-		                   (long long)n, d_res, ctx->dev, ctx->d_err);
+		                   (long long)n, d_res, ctx->dev, ctx->d_err, min_count);
 	else return BMH_E_ARG;
 	BMH_HIP(ctx, hipGetLastError());
 	return BMH_OK;

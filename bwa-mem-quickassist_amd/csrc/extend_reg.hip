@@ -51,7 +51,7 @@ __global__ __launch_bounds__(64) void extend_reg_kernel(const uint8_t *__restric
                                                         const uint32_t *__restrict__ order,
                                                         const uint32_t *__restrict__ count, long long n,
                                                         bmh_ext_result_t *__restrict__ out, DevParams P,
-                                                        int *__restrict__ err_flag)
+                                                        int *__restrict__ err_flag, int max_count)
 {
 	__shared__ int smat[32]; // biased scores, read once per task while building the lane profiles
 	const int lane = threadIdx.x;
@@ -61,7 +61,8 @@ __global__ __launch_bounds__(64) void extend_reg_kernel(const uint8_t *__restric
 
 	if (lane < 25) smat[lane] = mat_at(P, lane) + bias;
 
-	if (count) n = *count; // bin size produced on the device by classify_kernel
+	if (count) n = *count; // bin size produced on the device by the dispatcher
+	if (max_count > 0 && n >= max_count) return; // a large bin is served by the lanes-per-task kernel instead
 	for (long long slot = blockIdx.x; slot < n; slot += gridDim.x) {
 		const uint32_t idx = order ? order[slot] : (uint32_t)slot;
 		const uint4 *tp = (const uint4 *)(tasks + idx);
@@ -236,13 +237,13 @@ __global__ __launch_bounds__(64) void extend_reg_kernel(const uint8_t *__restric
 
 // ---- launcher: every task listed in d_order[0..*d_count) (or 0..n) must have 1 <= qlen <= 64*ns
 int launch_extend_reg(bmh_ctx *ctx, int ns, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
-                      bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count)
+                      bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, int max_count)
 {
 	if (n <= 0) return BMH_OK;
 	const long long grid = n < kPersistentGrid ? n : kPersistentGrid;
 #define BMH_LAUNCH_REG(NS)                                                                                           \
 	hipLaunchKernelGGL(extend_reg_kernel<NS>, dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_pool, d_tasks, d_order, \
-	                   d_count, (long long)n, d_res, ctx->dev, ctx->d_err)
+	                   d_count, (long long)n, d_res, ctx->dev, ctx->d_err, max_count)
 	switch (ns) {
 	case 1: BMH_LAUNCH_REG(1); break;
 	case 2: BMH_LAUNCH_REG(2); break;
