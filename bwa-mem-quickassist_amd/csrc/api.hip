@@ -227,17 +227,6 @@ int bmh_extend_batch_device(bmh_ctx_t *ctx, const uint8_t *d_pool, const bmh_ext
 	return launch_extend(ctx, d_pool, d_tasks, n, d_res, d_order, ctx->qcap);
 }
 
-// longest-first launch order (LPT): rows dominate the cost, ksw.c:411
-static void lpt_order(const bmh_ext_task_t *t, int64_t n, std::vector<uint32_t> &ord)
-{
-	ord.resize((size_t)n);
-	std::iota(ord.begin(), ord.end(), 0u);
-	std::stable_sort(ord.begin(), ord.end(), [t](uint32_t a, uint32_t b) {
-		const uint32_t ka = (uint32_t)t[a].tlen * 2 + (t[a].qlen > 64), kb = (uint32_t)t[b].tlen * 2 + (t[b].qlen > 64);
-		return ka > kb;
-	});
-}
-
 static int validate_ext(bmh_ctx *ctx, const bmh_ext_task_t *t, int64_t n, size_t pool_bytes, int *qmax)
 {
 	int qm = 1;
@@ -277,20 +266,17 @@ int bmh_extend_batch(bmh_ctx_t *ctx, const uint8_t *pool, size_t pool_bytes, con
 	int qmax = 1, rc;
 	if ((rc = validate_ext(ctx, tasks, n, pool_bytes, &qmax))) return rc;
 	BMH_HIP(ctx, hipSetDevice(ctx->device));
-	std::vector<uint32_t> ord;
-	lpt_order(tasks, n, ord);
 	if (!resident) {
 		ctx->pool_resident = false;
 		if ((rc = ensure(ctx, ctx->d_pool, pool_bytes + 16))) return rc;
 	}
 	if ((rc = ensure(ctx, ctx->d_tasks, (size_t)n * sizeof(bmh_ext_task_t)))) return rc;
 	if ((rc = ensure(ctx, ctx->d_res, (size_t)n * sizeof(bmh_ext_result_t)))) return rc;
-	if ((rc = ensure(ctx, ctx->d_order, (size_t)n * 4))) return rc;
 	if (!resident) BMH_HIP(ctx, hipMemcpyAsync(ctx->d_pool.p, pool, pool_bytes, hipMemcpyHostToDevice, ctx->stream));
 	BMH_HIP(ctx, hipMemcpyAsync(ctx->d_tasks.p, tasks, (size_t)n * sizeof(bmh_ext_task_t), hipMemcpyHostToDevice, ctx->stream));
-	BMH_HIP(ctx, hipMemcpyAsync(ctx->d_order.p, ord.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+	// launch order: the dispatcher sorts the tasks on the device (bin, length bucket, row estimate)
 	if ((rc = launch_extend(ctx, (const uint8_t *)ctx->d_pool.p, (const bmh_ext_task_t *)ctx->d_tasks.p, n,
-	                        (bmh_ext_result_t *)ctx->d_res.p, (const uint32_t *)ctx->d_order.p, qmax)))
+	                        (bmh_ext_result_t *)ctx->d_res.p, nullptr, qmax)))
 		return rc;
 	BMH_HIP(ctx, hipMemcpyAsync(results, ctx->d_res.p, (size_t)n * sizeof(bmh_ext_result_t), hipMemcpyDeviceToHost, ctx->stream));
 	return fetch_err(ctx); // synchronises
@@ -324,7 +310,6 @@ int bmh_extend_batch_sharded(bmh_ctx_t *const *ctxs, int n_ctx, const uint8_t *p
 		if (!ctxs[g] || !ctxs[g]->have_params) return BMH_E_ARG;
 	if (n == 0) return BMH_OK;
 	// contiguous static split; every shard gets the whole pool (offsets stay valid), its own task slice
-	std::vector<std::vector<uint32_t>> ords((size_t)n_ctx);
 	std::vector<int64_t> lo((size_t)n_ctx + 1);
 	for (int g = 0; g <= n_ctx; ++g) lo[(size_t)g] = n * g / n_ctx;
 	int rc;
@@ -336,16 +321,13 @@ int bmh_extend_batch_sharded(bmh_ctx_t *const *ctxs, int n_ctx, const uint8_t *p
 		int qmax = 1;
 		if ((rc = validate_ext(c, t, m, pool_bytes, &qmax))) return rc;
 		BMH_HIP(c, hipSetDevice(c->device));
-		lpt_order(t, m, ords[(size_t)g]);
 		if ((rc = ensure(c, c->d_pool, pool_bytes + 16))) return rc;
 		if ((rc = ensure(c, c->d_tasks, (size_t)m * sizeof(bmh_ext_task_t)))) return rc;
 		if ((rc = ensure(c, c->d_res, (size_t)m * sizeof(bmh_ext_result_t)))) return rc;
-		if ((rc = ensure(c, c->d_order, (size_t)m * 4))) return rc;
 		BMH_HIP(c, hipMemcpyAsync(c->d_pool.p, pool, pool_bytes, hipMemcpyHostToDevice, c->stream));
 		BMH_HIP(c, hipMemcpyAsync(c->d_tasks.p, t, (size_t)m * sizeof(bmh_ext_task_t), hipMemcpyHostToDevice, c->stream));
-		BMH_HIP(c, hipMemcpyAsync(c->d_order.p, ords[(size_t)g].data(), (size_t)m * 4, hipMemcpyHostToDevice, c->stream));
 		if ((rc = launch_extend(c, (const uint8_t *)c->d_pool.p, (const bmh_ext_task_t *)c->d_tasks.p, m,
-		                        (bmh_ext_result_t *)c->d_res.p, (const uint32_t *)c->d_order.p, qmax)))
+		                        (bmh_ext_result_t *)c->d_res.p, nullptr, qmax)))
 			return rc;
 		BMH_HIP(c, hipMemcpyAsync(results + lo[(size_t)g], c->d_res.p, (size_t)m * sizeof(bmh_ext_result_t),
 		                          hipMemcpyDeviceToHost, c->stream));
@@ -398,23 +380,17 @@ int bmh_global_batch(bmh_ctx_t *ctx, const uint8_t *pool, size_t pool_bytes, con
 		wmax = std::max(wmax, std::min(x.w, (int)x.qlen)); // only min(qlen,2w+1) columns are ever stored
 	}
 	BMH_HIP(ctx, hipSetDevice(ctx->device));
-	std::vector<uint32_t> ord((size_t)n);
-	std::iota(ord.begin(), ord.end(), 0u);
-	std::stable_sort(ord.begin(), ord.end(), [tasks](uint32_t a, uint32_t b) { return tasks[a].tlen > tasks[b].tlen; });
 	if (!resident) {
 		ctx->pool_resident = false;
 		if ((rc = ensure(ctx, ctx->d_pool, pool_bytes + 16))) return rc;
 	}
 	if ((rc = ensure(ctx, ctx->d_tasks, (size_t)n * sizeof(bmh_glb_task_t)))) return rc;
 	if ((rc = ensure(ctx, ctx->d_res, (size_t)n * sizeof(bmh_glb_result_t)))) return rc;
-	if ((rc = ensure(ctx, ctx->d_order, (size_t)n * 4))) return rc;
 	if ((rc = ensure(ctx, ctx->d_cigar, (cigar_words + 4) * 4))) return rc;
 	if (!resident) BMH_HIP(ctx, hipMemcpyAsync(ctx->d_pool.p, pool, pool_bytes, hipMemcpyHostToDevice, ctx->stream));
 	BMH_HIP(ctx, hipMemcpyAsync(ctx->d_tasks.p, tasks, (size_t)n * sizeof(bmh_glb_task_t), hipMemcpyHostToDevice, ctx->stream));
-	BMH_HIP(ctx, hipMemcpyAsync(ctx->d_order.p, ord.data(), (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
 	if ((rc = launch_global(ctx, (const uint8_t *)ctx->d_pool.p, (const bmh_glb_task_t *)ctx->d_tasks.p, n,
-	                        (bmh_glb_result_t *)ctx->d_res.p, (uint32_t *)ctx->d_cigar.p, (const uint32_t *)ctx->d_order.p, qmax,
-	                        tmax, wmax)))
+	                        (bmh_glb_result_t *)ctx->d_res.p, (uint32_t *)ctx->d_cigar.p, nullptr, qmax, tmax, wmax)))
 		return rc;
 	BMH_HIP(ctx, hipMemcpyAsync(results, ctx->d_res.p, (size_t)n * sizeof(bmh_glb_result_t), hipMemcpyDeviceToHost, ctx->stream));
 	if (cigar_words)
