@@ -30,6 +30,10 @@ namespace bmh {
 #define BMH_LANE_HOIST_LIMIT 128
 #endif
 constexpr int kLaneHoistLimit = BMH_LANE_HOIST_LIMIT;
+#ifndef BMH_LANE_FAST_BLOCKS
+#define BMH_LANE_FAST_BLOCKS 0 /* measured: 5.34 ms vs 4.78 ms per 1M-read batch with it on (register pressure, code size) */
+#endif
+constexpr bool kLaneFastBlocks = BMH_LANE_FAST_BLOCKS; // unpredicated body for blocks interior to every live lane's interval
 // waves per SIMD the register allocator must leave room for (2nd launch-bounds argument)
 #ifndef BMH_LANE_WAVES
 #define BMH_LANE_WAVES(C) ((C) <= 32 ? 4 : (C) <= 64 ? 3 : 2)
@@ -38,7 +42,8 @@ constexpr int kLaneHoistLimit = BMH_LANE_HOIST_LIMIT;
 // per-bit select: mask ? a : b  (one v_bitop3_b32 on gfx950)
 __device__ __forceinline__ int bfi2(int mask, int a, int b) { return __builtin_amdgcn_bitop3_b32(mask, a, b, 0xca); }
 
-template <int C>
+// SYM: o_del+e_del == o_ins+e_ins (bwa's default) -> H-oe is computed once per cell for both gap states
+template <int C, bool SYM>
 __global__ __launch_bounds__(64, BMH_LANE_WAVES(C)) void extend_lane_kernel(const uint8_t *__restrict__ pool,
                                                          const bmh_ext_task_t *__restrict__ tasks,
                                                          const uint32_t *__restrict__ order,
@@ -150,6 +155,32 @@ __global__ __launch_bounds__(64, BMH_LANE_WAVES(C)) void extend_lane_kernel(cons
 		for (int b = 0; b < NB; ++b) {
 			// the block is needed by a lane iff [8b,8b+8) meets [beg,end]  (end itself receives eh[end])
 			if (__builtin_amdgcn_ballot_w64(lb < 8 * b + 8 && le >= 8 * b) == 0) continue;
+			// Interior block: every live lane has all 8 columns inside [beg,end) -> no predication needed (finished
+			// lanes may compute junk, their results are already written).  Edge blocks take the predicated body.
+			if (kLaneFastBlocks && __builtin_amdgcn_ballot_w64(alive && !(lb <= 8 * b && le >= 8 * b + 8)) == 0) {
+#pragma unroll
+				for (int c = 0; c < 8; ++c) {
+					const int p = 8 * b + c;
+#ifdef BMH_LANE_LDS_SEL
+					const unsigned sel = qsel[p * 64 + lane];
+#else
+					const unsigned sel = __builtin_amdgcn_perm((unsigned)QS[p / 4], C >= kLaneHoistLimit ? row.y : 0u,
+					                                           0x0c0c0c04u + (unsigned)(p % 4));
+#endif
+					const int sc = (int)(int8_t)__builtin_amdgcn_perm(row.y, row.x, sel);
+					const int e = (int)((unsigned)HE[p] >> 16);
+					const int h = max(max((int)(HE[p] & 0xffff) + sc, e), f);    // ksw.c:430-432
+					const int hod = h - oe_del, hoi = SYM ? hod : h - oe_ins;
+					const int en = max(max(e - e_del, hod), 0);                  // ksw.c:436-439
+					f = max(max(f - e_ins, hoi), 0);                             // ksw.c:441-444
+					HE[p] = en << 16 | hprev;
+					kmax = max(kmax, h << 16 | p);
+					nz[p / 32] |= (int)(min((unsigned)h, 1u) << (p % 32));
+					hprev = h;
+					if (p == C - 1) hlast = h;
+				}
+				continue;
+			}
 #pragma unroll
 			for (int c = 0; c < 8; ++c) {
 				const int p = 8 * b + c;
@@ -166,8 +197,9 @@ __global__ __launch_bounds__(64, BMH_LANE_WAVES(C)) void extend_lane_kernel(cons
 				const int e = (int)((unsigned)HE[p] >> 16);
 				const int hh = max((int)(HE[p] & 0xffff) + sc, e);          // ksw.c:430-431
 				const int h = max(hh, f);                                   // ksw.c:432
-				const int en = max(max(e - e_del, h - oe_del), 0) & actv;   // ksw.c:436-439
-				f = max(max(f - e_ins, h - oe_ins), 0) & actv;              // ksw.c:441-444
+				const int hod = h - oe_del, hoi = SYM ? hod : h - oe_ins;
+				const int en = max(max(e - e_del, hod), 0) & actv;          // ksw.c:436-439
+				f = max(max(f - e_ins, hoi), 0) & actv;                     // ksw.c:441-444
 				HE[p] = en << 16 | hprev;                                   // eh[j] = {H(i,j-1), E(i+1,j)}, ksw.c:429,440
 				const int ha = bfi2(actv, h, -1);                           // -1 outside the interval
 				kmax = max(kmax, ha << 16 | p);                             // row max, ties -> larger j (ksw.c:434)
@@ -225,9 +257,16 @@ int launch_extend_lane(bmh_ctx *ctx, int c, const uint8_t *d_pool, const bmh_ext
 {
 	if (n <= 0) return BMH_OK;
 	const long long grid = (n + 63) / 64; // blocks past the bin's device-side count return at once
-#define BMH_LAUNCH_LANE(CC)                                                                                         \
-	hipLaunchKernelGGL(extend_lane_kernel<CC>, dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_pool, d_tasks, d_order, \
-	                   d_count, (long long)n, d_res, ctx->dev, ctx->d_err)
+	const bool sym = ctx->dev.o_del + ctx->dev.e_del == ctx->dev.o_ins + ctx->dev.e_ins;
+#define BMH_LAUNCH_LANE(CC)                                                                                             \
+	do {                                                                                                                \
+		if (sym)                                                                                                        \
+			hipLaunchKernelGGL((extend_lane_kernel<CC, true>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_pool,  \
+			                   d_tasks, d_order, d_count, (long long)n, d_res, ctx->dev, ctx->d_err);                 \
+		else                                                                                                            \
+			hipLaunchKernelGGL((extend_lane_kernel<CC, false>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_pool, \
+			                   d_tasks, d_order, d_count, (long long)n, d_res, ctx->dev, ctx->d_err);                 \
+	} while (0)
 	switch (c) {
 	case 32: BMH_LAUNCH_LANE(32); break;
 	case 64: BMH_LAUNCH_LANE(64); break;
