@@ -217,7 +217,7 @@ def main():
         if os.path.exists(tpath):  # HBM bytes per launch from rocprofv3 PMC passes of this same command
             tj = json.load(open(tpath))
             for k, v in tj.get("kernels", {}).items():
-                if k in dom["kernel"] or dom["kernel"].split(" ")[0] in k:
+                if dom["kernel"].split(" ")[0].rstrip(">") in k:  # e.g. "extend_lane_kernel<128" in "bmh::extend_lane_kernel<128, true>"
                     traffic = v.get("hbm_bytes_per_launch")
         out = {
             "metric": "aligned reads/sec (seed-extension hot path, ksw_extend2 batches on GPU)",
