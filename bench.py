@@ -46,8 +46,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
+    # under torch.distributed.run (RANK set) the process group is always created -- also for one rank -- so the
+    # RCCL path is the same code at N=1,2,4,8; a bare `python bench.py` stays single-process
+    use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
@@ -85,7 +89,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     ctx.set_kernel_timing(True)  # HIP events around each extension kernel, on the launch stream
@@ -103,7 +107,7 @@ def main():
     step_kernels_ms = ev0.elapsed_time(ev1) / args.steps  # all kernels of a step, HIP events on the launch stream
     bin_ms = ctx.last_extend_bin_ms()                      # per kernel, last timed step
     ctx.sync()  # surfaces any BMH_E_RANGE flagged by the kernel
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed, reads_all, tasks_all = sh.reduce_report(elapsed, n_reads_used, n_tasks, dev)
 
@@ -246,7 +250,7 @@ def main():
         }
         if not parity_ok:
             out["value"] = 0.0  # a fast kernel with different results is not done
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

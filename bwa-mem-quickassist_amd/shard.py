@@ -19,7 +19,7 @@ def shard_ranges(n, world):
 
 def reduce_report(elapsed_s, n_reads, n_tasks, device=None):
     """max-over-ranks elapsed time, sum-over-ranks unit counts.  Works on NCCL(RCCL) and gloo."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return float(elapsed_s), float(n_reads), float(n_tasks)
     t = torch.tensor([elapsed_s], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
