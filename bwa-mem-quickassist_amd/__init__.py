@@ -21,7 +21,7 @@ DROPIN_PATH = os.path.join(_HERE, "libbwamem_hip_dropin.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "bwamem_hip.h")
 
 BMH_OK, BMH_E_NODEVICE, BMH_E_HIP, BMH_E_ARG, BMH_E_RANGE, BMH_E_NOMEM, BMH_E_CIGAR_CAP = 0, -1, -2, -3, -4, -5, -6
-BMH_F_QREV, BMH_F_TREV = 1, 2
+BMH_F_QREV, BMH_F_TREV, BMH_F_TPAC = 1, 2, 4
 
 # record layouts == include/bwamem_hip.h
 EXT_TASK = np.dtype([("q_off", "<u8"), ("t_off", "<u8"), ("qlen", "<u2"), ("tlen", "<u2"),
@@ -68,7 +68,7 @@ class _Read(C.Structure):
 
 
 class _DriverStats(C.Structure):
-    _fields_ = [(n, C.c_int64) for n in ("rounds", "ext_tasks", "seeds_extended", "seeds_skipped")]
+    _fields_ = [(n, C.c_int64) for n in ("rounds", "ext_tasks", "seeds_extended", "seeds_skipped", "pool_bytes")]
 
 
 _lib = None
@@ -90,6 +90,7 @@ def lib():
         L.bmh_ctx_set_params.argtypes = [C.c_void_p, C.c_void_p]
         L.bmh_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.bmh_ctx_set_qcap.argtypes = [C.c_void_p, C.c_int]
+        L.bmh_ctx_set_pac.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.bmh_set_kernel_timing.argtypes = [C.c_void_p, C.c_int]
         L.bmh_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.bmh_last_extend_bin_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
@@ -151,6 +152,14 @@ class Context:
 
     def set_stream(self, hip_stream_ptr):
         self._check(lib().bmh_ctx_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
+
+    def set_pac(self, pac, l_pac):
+        """Make the 2-bit reference resident on the device (BMH_F_TPAC tasks; drivers skip the host bns_get_seq).
+        The array is kept alive and must be passed unchanged to the drivers (they recognise it by address)."""
+        pac = np.ascontiguousarray(pac, dtype=np.uint8)
+        self._pac = pac
+        self._check(lib().bmh_ctx_set_pac(self._h, _ptr(pac), int(l_pac)))
+        return pac
 
     def set_qcap(self, q):
         self._check(lib().bmh_ctx_set_qcap(self._h, int(q)))

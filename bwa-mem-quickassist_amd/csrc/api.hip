@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <numeric>
 #include <vector>
 
@@ -125,6 +126,8 @@ int bmh_ctx_create(bmh_ctx_t **out, int device)
 	return BMH_OK;
 }
 
+static void pac_release(bmh_ctx_t *ctx);
+
 int bmh_ctx_destroy(bmh_ctx_t *ctx)
 {
 	if (!ctx) return BMH_OK;
@@ -132,6 +135,7 @@ int bmh_ctx_destroy(bmh_ctx_t *ctx)
 	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 	free_buf(ctx->d_pool), free_buf(ctx->d_tasks), free_buf(ctx->d_res), free_buf(ctx->d_order);
 	free_buf(ctx->d_cigar), free_buf(ctx->d_scratch), free_buf(ctx->d_bins), free_buf(ctx->d_zslab);
+	pac_release(ctx);
 	if (ctx->d_err) (void)hipFree(ctx->d_err);
 	if (ctx->h_err) (void)hipHostFree(ctx->h_err);
 	if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -163,6 +167,69 @@ int bmh_ctx_set_params(bmh_ctx_t *ctx, const bmh_params_t *p)
 	memcpy(d.matw, bytes, 28);
 	ctx->have_params = true;
 	return BMH_OK;
+}
+
+// The reference is immutable and large (hg38: 0.78 GB), and the reference program drives phase 1 from many host
+// threads, each with its own context: one device copy per (device, host buffer) is shared by all of them.
+struct PacShare {
+	int device;
+	const uint8_t *h;
+	long long l_pac;
+	void *d;
+	int refs;
+};
+static std::mutex g_pac_mu;
+static std::vector<PacShare> g_pacs;
+
+static void pac_release(bmh_ctx_t *ctx)
+{
+	if (!ctx->h_pac) return;
+	std::lock_guard<std::mutex> lk(g_pac_mu);
+	for (size_t i = 0; i < g_pacs.size(); ++i)
+		if (g_pacs[i].device == ctx->device && g_pacs[i].h == ctx->h_pac && g_pacs[i].l_pac == ctx->dev.l_pac) {
+			if (--g_pacs[i].refs == 0) {
+				(void)hipFree(g_pacs[i].d);
+				g_pacs.erase(g_pacs.begin() + (long)i);
+			}
+			break;
+		}
+	ctx->h_pac = nullptr, ctx->dev.pac = nullptr, ctx->dev.l_pac = 0;
+}
+
+int bmh_ctx_set_pac(bmh_ctx_t *ctx, const uint8_t *pac, int64_t l_pac)
+{
+	if (!ctx || !pac || l_pac <= 0) return BMH_E_ARG;
+	if (ctx->h_pac == pac && ctx->dev.l_pac == l_pac) return BMH_OK; // already resident
+	BMH_HIP(ctx, hipSetDevice(ctx->device));
+	pac_release(ctx);
+	std::lock_guard<std::mutex> lk(g_pac_mu);
+	for (auto &e : g_pacs)
+		if (e.device == ctx->device && e.h == pac && e.l_pac == l_pac) {
+			++e.refs;
+			ctx->h_pac = pac, ctx->dev.pac = (const uint8_t *)e.d, ctx->dev.l_pac = l_pac;
+			return BMH_OK;
+		}
+	const size_t bytes = (size_t)(l_pac / 4 + 1);
+	void *d = nullptr;
+	if (hipMalloc(&d, bytes + 16) != hipSuccess) {
+		(void)hipGetLastError();
+		ctx->last_error = "hipMalloc of " + std::to_string(bytes) + " bytes for the reference failed";
+		return BMH_E_NOMEM;
+	}
+	if (hipMemcpy(d, pac, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+		(void)hipFree(d);
+		ctx->last_error = "uploading the reference failed";
+		return BMH_E_HIP;
+	}
+	g_pacs.push_back({ctx->device, pac, (long long)l_pac, d, 1});
+	ctx->h_pac = pac, ctx->dev.pac = (const uint8_t *)d, ctx->dev.l_pac = l_pac;
+	return BMH_OK;
+}
+
+// does the context hold exactly this reference?  (internal hook for the C drivers)
+int bmh_ctx_has_pac_(const bmh_ctx_t *ctx, const uint8_t *pac, int64_t l_pac)
+{
+	return ctx && pac && ctx->h_pac == pac && ctx->dev.l_pac == l_pac;
 }
 
 int bmh_ctx_set_stream(bmh_ctx_t *ctx, void *s)
@@ -232,11 +299,16 @@ static int validate_ext(bmh_ctx *ctx, const bmh_ext_task_t *t, int64_t n, size_t
 	int qm = 1;
 	for (int64_t k = 0; k < n; ++k) {
 		const bmh_ext_task_t &x = t[k];
-		const bool qr = x.flags & BMH_F_QREV, tr = x.flags & BMH_F_TREV;
+		const bool qr = x.flags & BMH_F_QREV, tr = x.flags & BMH_F_TREV, tp = x.flags & BMH_F_TPAC;
 		const uint64_t qlo = qr ? x.q_off - (x.qlen ? x.qlen - 1 : 0) : x.q_off, thi_len = x.tlen;
 		const uint64_t tlo = tr ? x.t_off - (x.tlen ? x.tlen - 1 : 0) : x.t_off;
+		const uint64_t tspace = tp ? (uint64_t)(ctx->dev.l_pac << 1) : (uint64_t)pool_bytes;
+		if (tp && !ctx->dev.pac) {
+			ctx->last_error = "task " + std::to_string(k) + " has BMH_F_TPAC but no reference was uploaded (bmh_ctx_set_pac)";
+			return BMH_E_ARG;
+		}
 		if ((qr && x.qlen && x.q_off + 1 < x.qlen) || (tr && x.tlen && x.t_off + 1 < x.tlen) || qlo + x.qlen > pool_bytes ||
-		    tlo + thi_len > pool_bytes) {
+		    tlo + thi_len > tspace) {
 			ctx->last_error = "task " + std::to_string(k) + " reads outside the sequence pool";
 			return BMH_E_ARG;
 		}

@@ -23,6 +23,7 @@ struct bmh_ctx {
 	int qcap = 512; // query-length capacity used to size the LDS kernel's window state for *_device calls
 	// device workspaces of the host-buffer entry points
 	DevBuf d_pool, d_tasks, d_res, d_order, d_cigar, d_scratch;
+	const uint8_t *h_pac = nullptr; // host identity of the shared device copy of the 2-bit reference (bmh_ctx_set_pac)
 	DevBuf d_zslab; // direction words of the lane-per-task global kernels, one slab per resident wave
 	int glb_mode = 0; // 0 lane-per-task global kernels, 1 one wave per task only (env BMH_GLB_MODE=wave)
 	DevBuf d_bins; // per-launch bin lists of the extension dispatcher: 4 counters + 4 x n task indices

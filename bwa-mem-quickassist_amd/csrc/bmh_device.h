@@ -14,6 +14,8 @@ struct DevParams {
 	int max_mat;      // max entry of mat[] (ksw.c:398-400), precomputed on the host
 	int bias;         // -min(mat[]) floored at 0: profile bytes are stored as score+bias (unsigned)
 	uint32_t matw[7]; // mat[25] as bytes, little endian, padded to 28
+	const uint8_t *pac; // 2-bit reference resident in HBM (bmh_ctx_set_pac), or null
+	long long l_pac;    // its length in bases; the doubled coordinate [l_pac, 2*l_pac) is the reverse strand
 };
 
 constexpr int kScoreLimit = 32000; // h0 + qlen*max_mat must stay below this (16-bit lanes)
@@ -67,6 +69,19 @@ __device__ __forceinline__ int mat_at(const DevParams &P, int idx)
 __device__ __forceinline__ int seq_base(const uint8_t *pool, uint64_t off, int k, bool rev)
 {
 	return rev ? pool[off - (uint64_t)k] : pool[off + (uint64_t)k];
+}
+
+// target base k of a task.  With BMH_F_TPAC the offset is a position on bwa's doubled coordinate and the base is
+// decoded from the 2-bit pac on the fly -- bns_get_seq (reference bntseq.c:355-376) done by the consumer:
+// forward strand pac[p], reverse strand 3 - pac[2*l_pac-1-p].
+__device__ __forceinline__ int tgt_base(const uint8_t *pool, const DevParams &P, uint64_t off, int k, bool rev, bool tpac)
+{
+	if (!tpac) return seq_base(pool, off, k, rev);
+	const long long p = rev ? (long long)off - k : (long long)off + k;
+	const bool rs = p >= P.l_pac;
+	const long long f = rs ? (P.l_pac << 1) - 1 - p : p;
+	const int b = P.pac[f >> 2] >> ((~f & 3) << 1) & 3;
+	return rs ? 3 - b : b;
 }
 
 // ksw.c:401-405 without floating point: trunc((x)/e + 1) floored at 1 equals x/e+1 for x>=0, else 1 (e>=1)

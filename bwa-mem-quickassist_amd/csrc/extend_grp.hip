@@ -104,7 +104,7 @@ __global__ __launch_bounds__(64) void extend_grp_kernel(const uint8_t *__restric
 				h0 = max((int)tb.y, 0); // ksw.c:384
 				w = (int)(int16_t)(tb.z & 0xffff);
 				const int end_bonus = (int)(int16_t)(tb.z >> 16);
-				const bool qrev = tb.w & BMH_F_QREV, trev = tb.w & BMH_F_TREV;
+				const bool qrev = tb.w & BMH_F_QREV, trev = tb.w & BMH_F_TREV, tpac = tb.w & BMH_F_TPAC;
 				if (qlen > NC || qlen < 1 || tlen > kGrpTcap || h0 + qlen * P.max_mat > kScoreLimit) {
 					if (l16 == 0) {
 						int *p = (int *)(out + idx);
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(64) void extend_grp_kernel(const uint8_t *__restric
 					for (int r = l16 * 4; r < tlen; r += 64) { // stage the target strip, 4 bases per lane and turn
 #pragma unroll
 						for (int c = 0; c < 4; ++c)
-							if (r + c < tlen) tstage[g][r + c] = (uint8_t)seq_base(pool, t_off, r + c, trev);
+							if (r + c < tlen) tstage[g][r + c] = (uint8_t)tgt_base(pool, P, t_off, r + c, trev, tpac);
 					}
 					w = min(w, max(1, band_cap(qlen, P.max_mat, end_bonus, P.o_ins, e_ins))); // ksw.c:398-406
 					w = min(w, max(1, band_cap(qlen, P.max_mat, end_bonus, P.o_del, e_del)));

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(64, BMH_LANE_WAVES(C)) void extend_lane_kernel(cons
 	const int h0 = max((int)tb.y, 0); // ksw.c:384
 	int w = (int)(int16_t)(tb.z & 0xffff);
 	const int end_bonus = (int)(int16_t)(tb.z >> 16);
-	const bool qrev = tb.w & BMH_F_QREV, trev = tb.w & BMH_F_TREV;
+	const bool qrev = tb.w & BMH_F_QREV, trev = tb.w & BMH_F_TREV, tpac = tb.w & BMH_F_TPAC;
 	const bool bad = qlen > C || qlen < 1 || h0 + qlen * P.max_mat > kScoreLimit;
 	if (valid && bad) {
 		int *p = (int *)(out + idx);
@@ -129,12 +129,12 @@ __global__ __launch_bounds__(64, BMH_LANE_WAVES(C)) void extend_lane_kernel(cons
 		int *p = (int *)(out + idx);
 		p[0] = h0, p[1] = 0, p[2] = 0, p[3] = 0, p[4] = -1, p[5] = 0;
 	}
-	int tnext = alive ? seq_base(pool, t_off, 0, trev) : 0;
+	int tnext = alive ? tgt_base(pool, P, t_off, 0, trev, tpac) : 0;
 
 	for (int i = 0; __builtin_amdgcn_ballot_w64(alive) != 0; ++i) { // i is wave-uniform: all tasks started together
 		const int tcur = tnext;
 		tnext = 0;
-		if (alive && i + 1 < tlen) tnext = seq_base(pool, t_off, i + 1, trev); // consumed one row later
+		if (alive && i + 1 < tlen) tnext = tgt_base(pool, P, t_off, i + 1, trev, tpac); // consumed one row later
 		const uint2 row = srow[min(tcur, 4)];
 		begp = max(begp, i - w + off);     // ksw.c:418-420
 		endp = min(endp, i + w + 1 + off); // endp <= C covers the qlen clamp

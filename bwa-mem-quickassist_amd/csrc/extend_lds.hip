@@ -60,7 +60,7 @@ __global__ __launch_bounds__(64) void extend_lds_kernel(const uint8_t *__restric
 		int h0 = uni(tb.y);
 		int w = uni((int)(int16_t)(tb.z & 0xffff));
 		const int end_bonus = uni((int)(int16_t)(tb.z >> 16));
-		const bool qrev = uni(tb.w) & BMH_F_QREV, trev = uni(tb.w) & BMH_F_TREV;
+		const bool qrev = uni(tb.w) & BMH_F_QREV, trev = uni(tb.w) & BMH_F_TREV, tpac = uni(tb.w) & BMH_F_TPAC;
 		if (h0 < 0) h0 = 0; // ksw.c:384
 
 		if (qlen > qcap || h0 + qlen * P.max_mat > kScoreLimit) { // outside the supported range: fail loudly
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(64) void extend_lds_kernel(const uint8_t *__restric
 				tv = 0;
 				for (int k = 0; k < 4; ++k) {
 					const int r = i + lane * 4 + k;
-					if (r < tlen) tv |= (uint32_t)seq_base(pool, t_off, r, trev) << (8 * k);
+					if (r < tlen) tv |= (uint32_t)tgt_base(pool, P, t_off, r, trev, tpac) << (8 * k);
 				}
 			}
 			const int tw = __builtin_amdgcn_readlane((int)tv, (i >> 2) & 63);

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(64) void extend_reg_kernel(const uint8_t *__restric
 		int h0 = uni(tb.y);
 		int w = uni((int)(int16_t)(tb.z & 0xffff));
 		const int end_bonus = uni((int)(int16_t)(tb.z >> 16));
-		const bool qrev = uni(tb.w) & BMH_F_QREV, trev = uni(tb.w) & BMH_F_TREV;
+		const bool qrev = uni(tb.w) & BMH_F_QREV, trev = uni(tb.w) & BMH_F_TREV, tpac = uni(tb.w) & BMH_F_TPAC;
 		if (h0 < 0) h0 = 0; // ksw.c:384
 
 		if (qlen > 64 * NS || qlen < 1 || h0 + qlen * P.max_mat > kScoreLimit) {
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(64) void extend_reg_kernel(const uint8_t *__restric
 			{
 				const int r = ib + lane;
 				int tbse = 0;
-				if (r < tlen) tbse = seq_base(pool, t_off, r, trev);
+				if (r < tlen) tbse = tgt_base(pool, P, t_off, r, trev, tpac);
 				tv = 0x0c0c0c00 | tbse;
 			}
 			const int nrow = min(64, tlen - ib);

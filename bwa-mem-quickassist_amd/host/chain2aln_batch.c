@@ -31,6 +31,7 @@
 
 int bmh_upload_pool(bmh_ctx_t *ctx, const uint8_t *pool, size_t bytes);
 const bmh_params_t *bmh_ctx_params_(const bmh_ctx_t *ctx);
+int bmh_ctx_has_pac_(const bmh_ctx_t *ctx, const uint8_t *pac, int64_t l_pac);
 void bmh_ctx_set_driver_stats_(bmh_ctx_t *ctx, const bmh_driver_stats_t *st);
 
 #define MAX_BAND_TRY 2 /* bwamem.c:493 */
@@ -136,6 +137,7 @@ typedef struct {
 	void *pre_ud;
 	bmh_alnreg_v *regs;
 	const chain_win_t *wins;
+	int tpac; /* targets come from the device-resident pac */
 	bmh_driver_stats_t st;
 	int err;
 } drv_t;
@@ -150,11 +152,12 @@ static int emit_left(drv_t *d, int r, rstate_t *rs, bmh_ext_task_t *t)
 	if (rs->aw0 > 32767) return BMH_E_RANGE;
 	memset(t, 0, sizeof(*t));
 	t->q_off = rs->read_off + (uint64_t)(s->qbeg - 1); /* query[qbeg-1-i], bwamem.c:814 */
-	t->t_off = cw->win_off + (uint64_t)(tl > 0 ? tl - 1 : 0); /* rseq[tmp-1-i], bwamem.c:817 */
+	if (d->tpac) t->t_off = (uint64_t)(tl > 0 ? s->rbeg - 1 : cw->rmax0); /* same bases, read from the resident pac */
+	else t->t_off = cw->win_off + (uint64_t)(tl > 0 ? tl - 1 : 0);       /* rseq[tmp-1-i], bwamem.c:817 */
 	t->qlen = (uint16_t)s->qbeg, t->tlen = (uint16_t)tl;
 	t->h0 = s->len * d->p->a;
 	t->w = (int16_t)rs->aw0, t->end_bonus = (int16_t)d->p->pen_clip5;
-	t->flags = BMH_F_QREV | BMH_F_TREV;
+	t->flags = BMH_F_QREV | BMH_F_TREV | (d->tpac ? BMH_F_TPAC : 0);
 	(void)r;
 	return 0;
 }
@@ -170,7 +173,8 @@ static int emit_right(drv_t *d, int r, rstate_t *rs, bmh_ext_task_t *t)
 	if (rs->aw1 > 32767) return BMH_E_RANGE;
 	memset(t, 0, sizeof(*t));
 	t->q_off = rs->read_off + (uint64_t)qe;
-	t->t_off = cw->win_off + (uint64_t)re;
+	t->t_off = d->tpac ? (uint64_t)(cw->rmax0 + re) : cw->win_off + (uint64_t)re;
+	t->flags = d->tpac ? BMH_F_TPAC : 0;
 	t->qlen = (uint16_t)(l_query - qe), t->tlen = (uint16_t)tl;
 	t->h0 = rs->sc0;
 	t->w = (int16_t)rs->aw1, t->end_bonus = (int16_t)d->p->pen_clip3;
@@ -363,7 +367,10 @@ int bmh_chain2aln_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n
 			if (cw->rmax1 < cw->rmax0) { rc = BMH_E_ARG; goto done; }
 		}
 	}
-	for (ci_flat = 0; ci_flat < n_chains; ++ci_flat) {
+	/* with the reference resident on the device (bmh_ctx_set_pac) the tasks address it directly and no window is
+	 * decoded or shipped: bns_get_seq (bwamem.c:757) happens inside the kernels */
+	d.tpac = bmh_ctx_has_pac_(ctx, pac, l_pac);
+	for (ci_flat = 0; ci_flat < n_chains && !d.tpac; ++ci_flat) {
 		wins[ci_flat].win_off = pool_bytes;
 		pool_bytes += (size_t)(wins[ci_flat].rmax1 - wins[ci_flat].rmax0);
 	}
@@ -376,10 +383,11 @@ int bmh_chain2aln_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n
 	owner = (int *)malloc(sizeof(int) * (size_t)n_reads);
 	if (!pool || !tasks || !res || !owner) { rc = BMH_E_NOMEM; goto done; }
 	for (r = 0; r < n_reads; ++r) memcpy(pool + rs[r].read_off, reads[r].seq, (size_t)reads[r].l_seq);
-	for (ci_flat = 0; ci_flat < n_chains; ++ci_flat)
+	for (ci_flat = 0; ci_flat < n_chains && !d.tpac; ++ci_flat)
 		if (wins[ci_flat].rmax1 > wins[ci_flat].rmax0)
 			fetch_window(l_pac, pac, wins[ci_flat].rmax0, wins[ci_flat].rmax1, pool + wins[ci_flat].win_off);
 	memset(pool + pool_bytes, 0, 16);
+	d.st.pool_bytes = (int64_t)pool_bytes + 16;
 	if ((rc = bmh_upload_pool(ctx, pool, pool_bytes + 16))) goto done;
 
 	/* rounds */

@@ -81,6 +81,11 @@ bmh_alnreg_v *mem_align1_core_batched(const ref_mem_opt_t *opt, const void *bwt,
 	p.a = opt->a, p.w = opt->w, p.pen_clip5 = opt->pen_clip5, p.pen_clip3 = opt->pen_clip3;
 	memcpy(p.mat, opt->mat, 25);
 	ctx = bmh_tls_ctx(&p);
+	{ /* reference resident in HBM, shared by all threads: the kernels do bns_get_seq themselves.  BMH_PAC_RESIDENT=0
+	   * falls back to host-decoded windows in the pool. */
+		const char *e = getenv("BMH_PAC_RESIDENT");
+		if (!(e && e[0] == '0') && (rc = bmh_ctx_set_pac(ctx, pac, bns->l_pac))) bmh_tls_die(bmh_last_error(ctx), rc);
+	}
 	ud.opt = opt, ud.l_pac = bns->l_pac, ud.pac = pac, ud.reads = reads, ud.chains = chn;
 	if ((rc = bmh_chain2aln_batch(ctx, bns->l_pac, pac, batch_size, reads, chn, pre_short, &ud, regs))) /* bwamem.c:1110 */
 		bmh_tls_die(bmh_last_error(ctx), rc);

@@ -66,6 +66,10 @@ typedef struct bmh_params {
  * (bwamem.c:813-817) are expressed without materialising them. */
 #define BMH_F_QREV 1u
 #define BMH_F_TREV 2u
+/* target taken from the 2-bit reference resident on the device (bmh_ctx_set_pac): t_off is then a position on
+ * bwa's doubled coordinate [0, 2*l_pac) (reference bntseq.c:355-376), walked forwards or, with BMH_F_TREV,
+ * backwards; no target bytes are needed in the pool */
+#define BMH_F_TPAC 4u
 typedef struct bmh_ext_task {
 	uint64_t q_off;    /* pool offset of query base 0                     */
 	uint64_t t_off;    /* pool offset of target base 0                    */
@@ -116,6 +120,9 @@ int bmh_ctx_destroy(bmh_ctx_t *ctx);
 int bmh_ctx_set_params(bmh_ctx_t *ctx, const bmh_params_t *p);
 /* Run on a caller-owned hipStream_t (passed as void*); NULL restores the context's own. */
 int bmh_ctx_set_stream(bmh_ctx_t *ctx, void *hip_stream);
+/* Make the 2-bit packed reference (bwaidx_t.pac, reference bwa.h:16; l_pac/4+1 bytes) resident in HBM: enables
+ * BMH_F_TPAC tasks and lets the L3 drivers skip the host-side bns_get_seq.  hg38: 0.78 GB, uploaded once. */
+int bmh_ctx_set_pac(bmh_ctx_t *ctx, const uint8_t *pac, int64_t l_pac);
 int bmh_ctx_sync(bmh_ctx_t *ctx); /* waits for the stream; returns a pending BMH_E_RANGE/CIGAR_CAP of a *_device call */
 /* Capacity hint for the *_device entry points, which cannot look at the tasks on the host:
  * the longest query the launch must handle (default 512).  Longer tasks fail with BMH_E_RANGE. */
@@ -241,6 +248,7 @@ int bmh_reg2cigar_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, const
 /* Counters of the last bmh_chain2aln_batch call (for the bench / logs). */
 typedef struct bmh_driver_stats {
 	int64_t rounds, ext_tasks, seeds_extended, seeds_skipped;
+	int64_t pool_bytes; /* bytes of sequence shipped to the device for the call */
 } bmh_driver_stats_t;
 int bmh_driver_stats(const bmh_ctx_t *ctx, bmh_driver_stats_t *st);
 

@@ -213,11 +213,22 @@ int orc_global(const orc_scoring_t *sc, int qlen, const uint8_t *query,
 typedef struct {
 	const orc_scoring_t *sc;
 	const uint8_t *pool;
+	const uint8_t *pac; /* 2-bit reference for BMH_F_TPAC tasks, or NULL */
+	int64_t l_pac;
 	const bmh_ext_task_t *tasks;
 	bmh_ext_result_t *res;
 	int lo, hi;
 	int64_t cells;
 } ext_job_t;
+
+/* one base of bwa's doubled coordinate: forward strand pac[p], reverse strand the complement read backwards
+ * (what bns_get_seq returns base by base, reference bntseq.c:355-376) */
+static int pac_base(const uint8_t *pac, int64_t l_pac, int64_t p)
+{
+	if (p < l_pac) return pac[p >> 2] >> ((~p & 3) << 1) & 3;
+	p = (l_pac << 1) - 1 - p;
+	return 3 - (pac[p >> 2] >> ((~p & 3) << 1) & 3);
+}
 
 static void fetch_seq(const uint8_t *pool, uint64_t off, int len, int rev, uint8_t *dst)
 {
@@ -236,7 +247,11 @@ static void *ext_job_run(void *p)
 		orc_extend_out_t o;
 		orc_extend_stats_t st;
 		fetch_seq(job->pool, tk->q_off, tk->qlen, tk->flags & BMH_F_QREV, q);
-		fetch_seq(job->pool, tk->t_off, tk->tlen, tk->flags & BMH_F_TREV, t);
+		if (tk->flags & BMH_F_TPAC) {
+			int x;
+			for (x = 0; x < tk->tlen; ++x)
+				t[x] = (uint8_t)pac_base(job->pac, job->l_pac, tk->flags & BMH_F_TREV ? (int64_t)tk->t_off - x : (int64_t)tk->t_off + x);
+		} else fetch_seq(job->pool, tk->t_off, tk->tlen, tk->flags & BMH_F_TREV, t);
 		orc_extend(job->sc, tk->qlen, q, tk->tlen, t, tk->w, tk->end_bonus, tk->h0, &o, &st);
 		job->res[k].score = o.score, job->res[k].qle = o.qle, job->res[k].tle = o.tle;
 		job->res[k].gtle = o.gtle, job->res[k].gscore = o.gscore, job->res[k].max_off = o.max_off;
@@ -252,6 +267,13 @@ int orc_extend_batch(const orc_scoring_t *sc, const uint8_t *seqpool,
                      struct bmh_ext_result *results, int64_t *cells_out,
                      int nthreads)
 {
+	return orc_extend_batch_pac(sc, seqpool, 0, 0, tasks, n, results, cells_out, nthreads);
+}
+
+int orc_extend_batch_pac(const orc_scoring_t *sc, const uint8_t *seqpool, const uint8_t *pac, int64_t l_pac,
+                         const struct bmh_ext_task *tasks, int n, struct bmh_ext_result *results, int64_t *cells_out,
+                         int nthreads)
+{
 	int i;
 	int64_t cells = 0;
 	if (nthreads < 1) nthreads = 1;
@@ -261,6 +283,7 @@ int orc_extend_batch(const orc_scoring_t *sc, const uint8_t *seqpool,
 		pthread_t tid[256];
 		for (i = 0; i < nthreads; ++i) {
 			jobs[i].sc = sc, jobs[i].pool = seqpool, jobs[i].tasks = tasks, jobs[i].res = results;
+			jobs[i].pac = pac, jobs[i].l_pac = l_pac;
 			jobs[i].lo = (int)((int64_t)n * i / nthreads);
 			jobs[i].hi = (int)((int64_t)n * (i + 1) / nthreads);
 			jobs[i].cells = 0;

@@ -39,7 +39,7 @@ assert EXT_TASK.itemsize == 32 and EXT_RES.itemsize == 24
 assert GLB_TASK.itemsize == 32 and GLB_RES.itemsize == 8
 assert PARAMS.itemsize == 64 and SEED.itemsize == 16 and ALNREG.itemsize == 64
 
-BMH_F_QREV, BMH_F_TREV = 1, 2
+BMH_F_QREV, BMH_F_TREV, BMH_F_TPAC = 1, 2, 4
 
 
 def fill_scmat(a, b, n_score=-1):
@@ -92,6 +92,7 @@ def load_oracle():
         lib.orc_extend.restype = None
         lib.orc_global.restype = C.c_int
         lib.orc_extend_batch.restype = C.c_int
+        lib.orc_extend_batch_pac.restype = C.c_int
         lib.orc_chain2aln.restype = None
         lib.orc_get_seq.restype = C.c_void_p
         lib.orc_cal_max_gap.restype = C.c_int
@@ -155,18 +156,21 @@ def ref_extend_batch(p, pool, tasks):
     return out
 
 
-def orc_extend_batch(p, pool, tasks, nthreads=1):
-    """Run OUR restatement on every task; returns (results, total_cells)."""
+def orc_extend_batch(p, pool, tasks, nthreads=1, pac=None, l_pac=0):
+    """Run OUR restatement on every task; returns (results, total_cells).  `pac`/`l_pac` serve BMH_F_TPAC tasks."""
     lib = load_oracle()
+    if pac is not None:
+        pac = np.ascontiguousarray(pac, dtype=np.uint8)
     keep = []
     sc = scoring_of(p, keep)
     tasks = np.ascontiguousarray(tasks)
     pool = np.ascontiguousarray(pool)
     out = np.zeros(len(tasks), dtype=EXT_RES)
     cells = C.c_int64(0)
-    lib.orc_extend_batch(C.byref(sc), pool.ctypes.data_as(C.c_void_p), tasks.ctypes.data_as(C.c_void_p),
-                         C.c_int(len(tasks)), out.ctypes.data_as(C.c_void_p), C.byref(cells),
-                         C.c_int(nthreads))
+    lib.orc_extend_batch_pac(C.byref(sc), pool.ctypes.data_as(C.c_void_p),
+                             pac.ctypes.data_as(C.c_void_p) if pac is not None else None, C.c_int64(l_pac),
+                             tasks.ctypes.data_as(C.c_void_p), C.c_int(len(tasks)), out.ctypes.data_as(C.c_void_p),
+                             C.byref(cells), C.c_int(nthreads))
     return out, cells.value
 
 
