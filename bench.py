@@ -32,6 +32,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--reads", type=int, default=1_000_000, help="simulated reads per GPU per step")
     ap.add_argument("--workload", default="150bp", choices=["150bp", "mixed100-300"])
+    ap.add_argument("--target-source", default="pool", choices=["pool", "pac"],
+                    help="pac: targets decoded on the fly from a 2-bit reference resident in HBM (BMH_F_TPAC)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (rank 0, N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--global-tasks", type=int, default=250_000,
@@ -69,6 +71,15 @@ def main():
     n_tasks = len(tasks)
     n_reads_used = int(len(np.unique(tread)))
     gen_s = time.time() - t0
+    pac, l_pac = None, 0
+    if args.target_source == "pac":
+        # the byte pool doubles as the forward strand of a synthetic genome: same tasks, same answers, but the
+        # kernels fetch target bases from the packed copy (position on the doubled coordinate = pool offset)
+        l_pac = len(pool)
+        q = np.concatenate([pool & 3, np.zeros((-l_pac) % 4 + 4, np.uint8)])
+        q = q[: len(q) // 4 * 4].reshape(-1, 4)
+        pac = (q[:, 0] << 6 | q[:, 1] << 4 | q[:, 2] << 2 | q[:, 3]).astype(np.uint8)
+        tasks["flags"] |= pkg.BMH_F_TPAC
     alg_bytes = int(tasks["qlen"].astype(np.int64).sum() + tasks["tlen"].astype(np.int64).sum() + 56 * n_tasks)
 
     d_pool = torch.from_numpy(pool).to(dev)
@@ -77,6 +88,8 @@ def main():
 
     ctx = pkg.Context(local_rank, params)
     ctx.set_qcap(int(tasks["qlen"].max()))
+    if pac is not None:
+        ctx.set_pac(pac, l_pac)
     # a dedicated (non-null) torch stream: the kernel is launched on it through the C-ABI and the
     # HIP events that time it are recorded on the same stream
     stream = torch.cuda.Stream(dev)
@@ -164,19 +177,19 @@ def main():
         ncores = os.cpu_count() or 1
         cpu = None
         sample_n = min(n_tasks, 20000)
-        want, cells = kswlib.orc_extend_batch(params, pool, tasks[:sample_n], nthreads=ncores)
+        want, cells = kswlib.orc_extend_batch(params, pool, tasks[:sample_n], nthreads=ncores, pac=pac, l_pac=l_pac)
         parity_ok = bool((want == res[:sample_n]).all())
         cells_per_task = cells / max(sample_n, 1)
         if world == 1 and not args.no_cpu_baseline:
             rate = None
             t1 = time.perf_counter()
-            kswlib.orc_extend_batch(params, pool, tasks[:sample_n], nthreads=ncores)
+            kswlib.orc_extend_batch(params, pool, tasks[:sample_n], nthreads=ncores, pac=pac, l_pac=l_pac)
             rate = sample_n / (time.perf_counter() - t1)
             big = int(min(n_tasks, max(sample_n, rate * args.cpu_seconds)))
             reps = max(1, int(rate * args.cpu_seconds / big))  # whole passes over the sample, ~cpu_seconds in all
             t1 = time.perf_counter()
             for _ in range(reps):
-                want2, cells2 = kswlib.orc_extend_batch(params, pool, tasks[:big], nthreads=ncores)
+                want2, cells2 = kswlib.orc_extend_batch(params, pool, tasks[:big], nthreads=ncores, pac=pac, l_pac=l_pac)
             dt = time.perf_counter() - t1
             parity_ok = parity_ok and bool((want2 == res[:big]).all())
             cells_per_task = cells2 / big
@@ -232,7 +245,7 @@ def main():
                                    f"as mem_chain2aln builds them (taskgen.c, SURVEY.md §8d)",
                        "reads_per_gpu": args.reads, "tasks_per_gpu": n_tasks,
                        "mean_qlen": float(tasks["qlen"].mean()), "mean_tlen": float(tasks["tlen"].mean()),
-                       "parallelism": f"static shard x{world}, no collective"},
+                       "target_source": args.target_source, "parallelism": f"static shard x{world}, no collective"},
             "tasks_per_s": tasks_all * args.steps / elapsed,
             "gcups": cells_per_task * tasks_all * args.steps / elapsed / 1e9,
             "parity": "bit-exact vs oracle on sampled tasks" if parity_ok else "MISMATCH vs oracle",
