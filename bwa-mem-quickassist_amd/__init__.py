@@ -21,7 +21,7 @@ DROPIN_PATH = os.path.join(_HERE, "libbwamem_hip_dropin.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "bwamem_hip.h")
 
 BMH_OK, BMH_E_NODEVICE, BMH_E_HIP, BMH_E_ARG, BMH_E_RANGE, BMH_E_NOMEM, BMH_E_CIGAR_CAP = 0, -1, -2, -3, -4, -5, -6
-BMH_F_QREV, BMH_F_TREV, BMH_F_TPAC = 1, 2, 4
+BMH_F_QREV, BMH_F_TREV, BMH_F_TPAC, BMH_F_QCOMP = 1, 2, 4, 8
 
 # record layouts == include/bwamem_hip.h
 EXT_TASK = np.dtype([("q_off", "<u8"), ("t_off", "<u8"), ("qlen", "<u2"), ("tlen", "<u2"),
@@ -32,6 +32,11 @@ EXT_RES = np.dtype([("score", "<i4"), ("qle", "<i4"), ("tle", "<i4"), ("gtle", "
 GLB_TASK = np.dtype([("q_off", "<u8"), ("t_off", "<u8"), ("qlen", "<u2"), ("tlen", "<u2"),
                      ("w", "<i4"), ("cigar_off", "<u4"), ("cigar_cap", "<u4")])
 GLB_RES = np.dtype([("score", "<i4"), ("n_cigar", "<i4")])
+SW_TASK = np.dtype([("q_off", "<u8"), ("t_off", "<u8"), ("tlen", "<u4"), ("qlen", "<u2"), ("flags", "<u2"),
+                    ("xtra", "<u4"), ("rsv", "<u4")])
+SW_RES = np.dtype([("score", "<i4"), ("te", "<i4"), ("qe", "<i4"), ("score2", "<i4"), ("te2", "<i4"),
+                   ("tb", "<i4"), ("qb", "<i4"), ("rsv", "<i4")])
+KSW_XBYTE, KSW_XSTOP, KSW_XSUBO, KSW_XSTART = 0x10000, 0x20000, 0x40000, 0x80000  # reference ksw.h:6-9
 PARAMS = np.dtype([("o_del", "<i4"), ("e_del", "<i4"), ("o_ins", "<i4"), ("e_ins", "<i4"),
                    ("zdrop", "<i4"), ("a", "<i4"), ("w", "<i4"), ("pen_clip5", "<i4"),
                    ("pen_clip3", "<i4"), ("mat", "i1", (25,)), ("pad", "i1", (3,))])
@@ -97,6 +102,8 @@ def lib():
         L.bmh_upload_pool.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.bmh_extend_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int64, C.c_void_p]
         L.bmh_extend_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.bmh_sw_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int64, C.c_void_p]
+        L.bmh_sw_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.bmh_extend_batch_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,
                                                C.c_int64, C.c_void_p]
         L.bmh_global_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int64, C.c_void_p,
@@ -200,6 +207,17 @@ class Context:
         return res, cig
 
     # ---- L2, device-resident (raw device pointers, e.g. torch tensors' data_ptr())
+    def sw_batch(self, pool, tasks):
+        """N x ksw_align2 (reference ksw.c:341; mate rescue / short chains).  numpy in, numpy out (kswr_t fields)."""
+        pool = np.ascontiguousarray(pool, dtype=np.uint8)
+        tasks = np.ascontiguousarray(tasks, dtype=SW_TASK)
+        res = np.zeros(len(tasks), dtype=SW_RES)
+        self._check(lib().bmh_sw_batch(self._h, _ptr(pool), pool.nbytes, _ptr(tasks), len(tasks), _ptr(res)))
+        return res
+
+    def sw_batch_device(self, d_pool, d_tasks, n, d_res):
+        self._check(lib().bmh_sw_batch_device(self._h, C.c_void_p(d_pool), C.c_void_p(d_tasks), int(n), C.c_void_p(d_res)))
+
     def extend_batch_device(self, d_pool, d_tasks, n, d_res, d_order=0):
         self._check(lib().bmh_extend_batch_device(self._h, C.c_void_p(d_pool), C.c_void_p(d_tasks), int(n),
                                                   C.c_void_p(d_res), C.c_void_p(d_order) if d_order else None))

@@ -121,6 +121,7 @@ int bmh_ctx_create(bmh_ctx_t **out, int device)
 	ctx->stream = ctx->own_stream;
 	if (const char *m = getenv("BMH_EXT_MODE")) ctx->force_kernel = !strcmp(m, "lds") ? 1 : !strcmp(m, "reg") ? 2 : !strcmp(m, "grp") ? 3 : !strcmp(m, "lanex4") ? 4 : 0;
 	if (const char *m = getenv("BMH_GLB_MODE")) ctx->glb_mode = !strcmp(m, "wave") ? 1 : 0;
+	if (const char *m = getenv("BMH_SW_MODE")) ctx->sw_mode = !strcmp(m, "generic") ? 1 : 0;
 	if (const char *m = getenv("BMH_GRID_MULT")) ctx->grid_mult = atoi(m) > 0 ? atoi(m) : 1;
 	*out = ctx;
 	return BMH_OK;
@@ -134,7 +135,7 @@ int bmh_ctx_destroy(bmh_ctx_t *ctx)
 	(void)hipSetDevice(ctx->device);
 	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 	free_buf(ctx->d_pool), free_buf(ctx->d_tasks), free_buf(ctx->d_res), free_buf(ctx->d_order);
-	free_buf(ctx->d_cigar), free_buf(ctx->d_scratch), free_buf(ctx->d_bins), free_buf(ctx->d_zslab);
+	free_buf(ctx->d_cigar), free_buf(ctx->d_scratch), free_buf(ctx->d_bins), free_buf(ctx->d_zslab), free_buf(ctx->d_sw);
 	pac_release(ctx);
 	if (ctx->d_err) (void)hipFree(ctx->d_err);
 	if (ctx->h_err) (void)hipHostFree(ctx->h_err);
@@ -162,6 +163,11 @@ int bmh_ctx_set_params(bmh_ctx_t *ctx, const bmh_params_t *p)
 	int mn = 0;
 	for (int i = 0; i < 25; ++i) d.max_mat = std::max(d.max_mat, (int)p->mat[i]), mn = std::min(mn, (int)p->mat[i]);
 	d.bias = -mn;
+	{
+		int8_t lo = 127;
+		for (int i = 0; i < 25; ++i) lo = std::min(lo, p->mat[i]);
+		d.sw_shift = (uint8_t)(256 - (uint8_t)lo);
+	}
 	uint8_t bytes[28] = {0};
 	memcpy(bytes, p->mat, 25);
 	memcpy(d.matw, bytes, 28);
@@ -468,6 +474,68 @@ int bmh_global_batch(bmh_ctx_t *ctx, const uint8_t *pool, size_t pool_bytes, con
 	if (cigar_words)
 		BMH_HIP(ctx, hipMemcpyAsync(cigar_pool, ctx->d_cigar.p, cigar_words * 4, hipMemcpyDeviceToHost, ctx->stream));
 	return fetch_err(ctx);
+}
+
+// ------------------------------------------------------------------ local Smith-Waterman (ksw_align2)
+
+int bmh_sw_batch_device(bmh_ctx_t *ctx, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks, int64_t n,
+                        bmh_sw_result_t *d_res)
+{
+	if (!ctx || n < 0 || (n > 0 && (!d_pool || !d_tasks || !d_res))) return BMH_E_ARG;
+	if (!ctx->have_params) return BMH_E_ARG;
+	if (n > 0xffffffffLL) return BMH_E_ARG;
+	BMH_HIP(ctx, hipSetDevice(ctx->device));
+	return launch_sw(ctx, d_pool, d_tasks, n, d_res, -1, -1);
+}
+
+int bmh_sw_batch(bmh_ctx_t *ctx, const uint8_t *pool, size_t pool_bytes, const bmh_sw_task_t *tasks, int64_t n,
+                 bmh_sw_result_t *results)
+{
+	if (!ctx || n < 0 || (n > 0 && (!tasks || !results))) return BMH_E_ARG;
+	if (!ctx->have_params) return BMH_E_ARG;
+	if (n == 0) return BMH_OK;
+	if (n > 0xffffffffLL) return BMH_E_ARG;
+	const bool resident = pool == nullptr; // use the pool left on the device by bmh_upload_pool()
+	if (resident) {
+		if (!ctx->pool_resident) return BMH_E_ARG;
+		pool_bytes = ctx->pool_bytes;
+	}
+	int qmax = 1, tmax = 1, rc;
+	for (int64_t k = 0; k < n; ++k) {
+		const bmh_sw_task_t &x = tasks[k];
+		const bool qr = x.flags & BMH_F_QREV, tr = x.flags & BMH_F_TREV, tp = x.flags & BMH_F_TPAC;
+		const uint64_t qlo = qr ? x.q_off - (x.qlen ? x.qlen - 1 : 0) : x.q_off;
+		const uint64_t tlo = tr ? x.t_off - (x.tlen ? x.tlen - 1 : 0) : x.t_off;
+		const uint64_t tspace = tp ? (uint64_t)(ctx->dev.l_pac << 1) : (uint64_t)pool_bytes;
+		if (tp && !ctx->dev.pac) {
+			ctx->last_error = "task " + std::to_string(k) + " has BMH_F_TPAC but no reference was uploaded (bmh_ctx_set_pac)";
+			return BMH_E_ARG;
+		}
+		if ((qr && x.qlen && x.q_off + 1 < x.qlen) || (tr && x.tlen && x.t_off + 1 < x.tlen) || qlo + x.qlen > pool_bytes ||
+		    tlo + x.tlen > tspace || x.tlen > 0x7fffffffu) {
+			ctx->last_error = "Smith-Waterman task " + std::to_string(k) + " reads outside the sequence pool";
+			return BMH_E_ARG;
+		}
+		if (x.qlen < 1 || (int64_t)x.qlen * ctx->dev.max_mat >= kScoreLimit) {
+			ctx->last_error = "Smith-Waterman task " + std::to_string(k) + ": qlen must be >= 1 and qlen*max(mat) below the 16-bit score range";
+			return BMH_E_RANGE;
+		}
+		qmax = std::max(qmax, (int)x.qlen), tmax = std::max(tmax, (int)x.tlen);
+	}
+	BMH_HIP(ctx, hipSetDevice(ctx->device));
+	if (!resident) {
+		ctx->pool_resident = false;
+		if ((rc = ensure(ctx, ctx->d_pool, pool_bytes + 16))) return rc;
+	}
+	if ((rc = ensure(ctx, ctx->d_tasks, (size_t)n * sizeof(bmh_sw_task_t)))) return rc;
+	if ((rc = ensure(ctx, ctx->d_res, (size_t)n * sizeof(bmh_sw_result_t)))) return rc;
+	if (!resident) BMH_HIP(ctx, hipMemcpyAsync(ctx->d_pool.p, pool, pool_bytes, hipMemcpyHostToDevice, ctx->stream));
+	BMH_HIP(ctx, hipMemcpyAsync(ctx->d_tasks.p, tasks, (size_t)n * sizeof(bmh_sw_task_t), hipMemcpyHostToDevice, ctx->stream));
+	if ((rc = launch_sw(ctx, (const uint8_t *)ctx->d_pool.p, (const bmh_sw_task_t *)ctx->d_tasks.p, n,
+	                    (bmh_sw_result_t *)ctx->d_res.p, qmax, tmax)))
+		return rc;
+	BMH_HIP(ctx, hipMemcpyAsync(results, ctx->d_res.p, (size_t)n * sizeof(bmh_sw_result_t), hipMemcpyDeviceToHost, ctx->stream));
+	return fetch_err(ctx); // synchronises
 }
 
 int bmh_driver_stats(const bmh_ctx_t *ctx, bmh_driver_stats_t *st)

@@ -24,8 +24,10 @@ struct bmh_ctx {
 	// device workspaces of the host-buffer entry points
 	DevBuf d_pool, d_tasks, d_res, d_order, d_cigar, d_scratch;
 	const uint8_t *h_pac = nullptr; // host identity of the shared device copy of the 2-bit reference (bmh_ctx_set_pac)
+	DevBuf d_sw;    // row / row-maximum slabs of the local Smith-Waterman kernels
 	DevBuf d_zslab; // direction words of the lane-per-task global kernels, one slab per resident wave
 	int glb_mode = 0; // 0 lane-per-task global kernels, 1 one wave per task only (env BMH_GLB_MODE=wave)
+	int sw_mode = 0;  // 0 register kernels where they fit, 1 slab kernel only (env BMH_SW_MODE=generic)
 	DevBuf d_bins; // per-launch bin lists of the extension dispatcher: 4 counters + 4 x n task indices
 	int grid_mult = 1;    // env BMH_GRID_MULT: persistent grid = resident waves x this (tuning knob)
 	int force_kernel = 0; // kernels for qlen<=128: 0 lane-per-task, 1 LDS kernel, 2 one task/wave, 3 four tasks/wave (env BMH_EXT_MODE=lds|reg|grp)
@@ -76,6 +78,10 @@ int launch_extend_grp(bmh_ctx *ctx, int nv, const uint8_t *d_pool, const bmh_ext
                       bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count);
 int launch_extend_lanex(bmh_ctx *ctx, int lpt, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
                         bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, int min_count);
+int launch_sw(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks, int64_t n, bmh_sw_result_t *d_res,
+              int qcap, int tcap);
+int launch_sw_generic(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks, int64_t n,
+                      bmh_sw_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, int qcap, int tcap);
 int launch_extend_lane(bmh_ctx *ctx, int c, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
                        bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count);
 int launch_extend_reg(bmh_ctx *ctx, int ns, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,

@@ -13,6 +13,7 @@ struct DevParams {
 	int o_del, e_del, o_ins, e_ins, zdrop;
 	int max_mat;      // max entry of mat[] (ksw.c:398-400), precomputed on the host
 	int bias;         // -min(mat[]) floored at 0: profile bytes are stored as score+bias (unsigned)
+	int sw_shift;     // ksw_qinit's byte-mode bias (uint8_t)(256 - min(mat)), reference ksw.c:78-85
 	uint32_t matw[7]; // mat[25] as bytes, little endian, padded to 28
 	const uint8_t *pac; // 2-bit reference resident in HBM (bmh_ctx_set_pac), or null
 	long long l_pac;    // its length in bases; the doubled coordinate [l_pac, 2*l_pac) is the reverse strand

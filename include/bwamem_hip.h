@@ -252,6 +252,46 @@ typedef struct bmh_driver_stats {
 } bmh_driver_stats_t;
 int bmh_driver_stats(const bmh_ctx_t *ctx, bmh_driver_stats_t *st);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Local Smith-Waterman for mate rescue and short chains.
+ * Replaces: kswr_t ksw_align2(qlen, query, tlen, target, m, mat, o_del, e_del, o_ins, e_ins, xtra, qry)
+ *           reference bwa-0.7.8/ksw.h:62, ksw.c:341-364 (over ksw_qinit / ksw_u8 / ksw_i16, ksw.c:62-331);
+ *           callers mem_matesw (bwamem_pair.c:109-175) and mem_chain2aln_short (bwamem.c:495-542).
+ * One record per call; `xtra` is passed through unchanged (KSW_XBYTE/XSTOP/XSUBO/XSTART | threshold, ksw.h:6-9)
+ * and the result is field for field kswr_t (ksw.h:14-19), including the byte-mode (16 columns per vector) versus
+ * word-mode (8) differences of the striped reference, which are visible in score2/te2 and, rarely, the scores.
+ * m = 5 and the matrix / gap penalties come from bmh_params_t.  Inputs outside the exact domain are refused with
+ * BMH_E_RANGE: qlen*max(mat) >= 32000, and byte-mode tasks that can overflow (qlen*max(mat) + shift >= 255) combined
+ * with KSW_XSTART, for which the reference reads uninitialised memory (ksw.c:355-357). */
+#define BMH_SW_XBYTE 0x10000u
+#define BMH_SW_XSTOP 0x20000u
+#define BMH_SW_XSUBO 0x40000u
+#define BMH_SW_XSTART 0x80000u
+/* query base = complement of the pool byte (3-b; N stays N).  With BMH_F_QREV the query is the reverse complement
+ * of the stored mate, so the host needs no second copy of it (reference bwamem_pair.c:130-133). */
+#define BMH_F_QCOMP 8u
+
+typedef struct bmh_sw_task {
+	uint64_t q_off;  /* query base k = pool[q_off + k], or pool[q_off - k] with BMH_F_QREV */
+	uint64_t t_off;  /* target likewise (BMH_F_TREV); with BMH_F_TPAC a doubled-coordinate position */
+	uint32_t tlen;
+	uint16_t qlen;
+	uint16_t flags;  /* BMH_F_QREV | BMH_F_TREV | BMH_F_TPAC | BMH_F_QCOMP */
+	uint32_t xtra;   /* ksw_align2's xtra */
+	uint32_t rsv;
+} bmh_sw_task_t; /* 32 bytes */
+
+typedef struct bmh_sw_result {
+	int32_t score, te, qe, score2, te2, tb, qb; /* kswr_t, ksw.h:14-19; unset values are -1 */
+	int32_t rsv;
+} bmh_sw_result_t; /* 32 bytes */
+
+int bmh_sw_batch(bmh_ctx_t *ctx, const uint8_t *pool, size_t pool_bytes, const bmh_sw_task_t *tasks, int64_t n,
+                 bmh_sw_result_t *results);
+/* device-resident variant: nothing crosses PCIe; completion is ordered on the context's stream */
+int bmh_sw_batch_device(bmh_ctx_t *ctx, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks, int64_t n,
+                        bmh_sw_result_t *d_results);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,7 +9,8 @@ mj / max_ie ties (low-complexity sequence), band re-growth and empty rows
 """
 import numpy as np
 
-from kswlib import EXT_TASK, GLB_TASK, BMH_F_QREV, BMH_F_TREV, make_params, fill_scmat
+from kswlib import (EXT_TASK, GLB_TASK, SW_TASK, BMH_F_QREV, BMH_F_TREV, BMH_F_QCOMP, KSW_XBYTE, KSW_XSTOP, KSW_XSUBO,
+                    KSW_XSTART, make_params, fill_scmat)
 
 
 def rand_seq(rng, n, p_n=0.0, alphabet=4):
@@ -199,3 +200,107 @@ def gen_glb_fuzz(rng, n):
         w = abs(len(q) - len(t)) + int(rng.choice([0, 1, 2, 5, 10, 30, 100, 200]))
         _add_glb(pb, q, t, w, rng.random() < 0.9)
     return finish_glb(pb)
+
+
+# ---- local Smith-Waterman (ksw_align2) ---------------------------------------------------------------------------
+def _add_sw(pb, rng, q, t, xtra, allow_flags=True):
+    """Stores q/t (optionally reversed and/or complemented in the pool, with the flag that undoes it)."""
+    qrev = allow_flags and rng.random() < 0.3
+    qcomp = allow_flags and rng.random() < 0.3
+    trev = allow_flags and rng.random() < 0.2
+    qs = np.where(q < 4, 3 - q, 4).astype(np.uint8) if qcomp else q
+    qo, to = pb.put(qs, qrev), pb.put(t, trev)
+    flags = (BMH_F_QREV if qrev else 0) | (BMH_F_TREV if trev else 0) | (BMH_F_QCOMP if qcomp else 0)
+    pb.tasks.append((qo, to, len(t), len(q), flags, xtra, 0))
+
+
+def sw_xtra_bwa(p, qlen):
+    """xtra exactly as mem_matesw / mem_chain2aln_short build it (reference bwamem_pair.c:147, bwamem.c:529)."""
+    a = int(p["a"])
+    return KSW_XSUBO | KSW_XSTART | (KSW_XBYTE if qlen * a < 250 else 0) | (19 * a)
+
+
+def gen_sw_materescue(rng, n, p, read_len=(150, 150), win=(300, 700), hit=0.7, hard=False):
+    """Mate-rescue shaped tasks (reference bwamem_pair.c:109-175): the mate against an insert-size window that
+    contains a mutated copy of it (or not), sometimes twice (-> score2), sometimes only partly."""
+    pb = PoolBuilder(SW_TASK)
+    for _ in range(n):
+        L = int(rng.integers(read_len[0], read_len[1] + 1))
+        W = int(rng.integers(win[0], win[1] + 1)) + L
+        t = rand_seq(rng, W)
+        if hard and rng.random() < 0.2:
+            t = rand_seq(rng, W, alphabet=2)  # low complexity: many ties
+        q = rand_seq(rng, L)
+        if rng.random() < hit:
+            st = int(rng.integers(0, W - L // 2))
+            src = t[st: st + L]
+            q2 = mutate(rng, src, sub=0.03 if not hard else 0.08, ins=0.004, dele=0.004, max_indel=6 if hard else 2)
+            k = int(rng.integers(0, L // 3)) if rng.random() < 0.3 else 0  # unrelated head
+            q = np.concatenate([rand_seq(rng, k), q2])[:L]
+            if len(q) < L:
+                q = np.concatenate([q, rand_seq(rng, L - len(q))])
+            if rng.random() < 0.25:  # a second, weaker copy elsewhere in the window
+                st2 = int(rng.integers(0, W - L))
+                cp = mutate(rng, src, sub=0.1)
+                t[st2: st2 + len(cp)] = cp[: W - st2]
+        if hard and rng.random() < 0.3:
+            q[rng.random(len(q)) < 0.04] = 4
+        if hard and rng.random() < 0.1:
+            t[rng.random(len(t)) < 0.02] = 4
+        _add_sw(pb, rng, q, t, sw_xtra_bwa(p, len(q)))
+    return pb.finish()
+
+
+def gen_sw_fuzz(rng, n, p):
+    """Function-level fuzz of ksw_align2: every xtra combination, tiny and ragged sizes, byte/word mode."""
+    pb = PoolBuilder(SW_TASK)
+    a, mx = int(p["a"]), int(np.max(p["mat"]))
+    shift = max(0, -int(np.min(p["mat"])))
+    for _ in range(n):
+        qlen = int(rng.choice([rng.integers(1, 20), rng.integers(20, 160), rng.integers(100, 300)]))
+        tlen = int(rng.choice([rng.integers(1, 30), rng.integers(30, 400), rng.integers(200, 900)]))
+        t = rand_seq(rng, tlen)
+        if rng.random() < 0.7 and tlen > 5:
+            st = int(rng.integers(0, tlen))
+            core = mutate(rng, t[st: st + min(qlen, tlen - st)], sub=float(rng.choice([0.0, 0.02, 0.1, 0.3])),
+                          ins=0.01, dele=0.01, max_indel=7)
+            q = np.concatenate([rand_seq(rng, int(rng.integers(0, max(1, qlen - len(core) + 1)))), core])[:qlen]
+            if len(q) < qlen:
+                q = np.concatenate([q, rand_seq(rng, qlen - len(q))])
+            if rng.random() < 0.2:
+                k = int(rng.integers(0, tlen))
+                t[k: k + len(core)] = core[: tlen - k]
+        else:
+            q = rand_seq(rng, qlen)
+        if rng.random() < 0.15:
+            q[rng.random(qlen) < 0.05] = 4
+        if rng.random() < 0.1:
+            t[rng.random(tlen) < 0.03] = 4
+        thr = int(rng.choice([0, 10, 19, 19 * a, 30, 60]))
+        xm = rng.random()
+        if xm < 0.6:
+            xtra = KSW_XSUBO | KSW_XSTART | thr
+        elif xm < 0.7:
+            xtra = KSW_XSTART
+        elif xm < 0.8:
+            xtra = KSW_XSUBO | thr
+        elif xm < 0.9:
+            xtra = KSW_XSTOP | thr
+        else:
+            xtra = 0
+        if rng.random() < 0.6 and (qlen * mx + shift < 255 or not (xtra & KSW_XSTART)):
+            xtra |= KSW_XBYTE  # byte mode; overflow (score 255) only where the reference defines the outcome
+        _add_sw(pb, rng, q, t, xtra)
+    return pb.finish()
+
+
+def sw_param_sets(rng, n):
+    """Parameter sets for ksw_align2 (o_ins >= 1: the closed-form domain of the GPU kernels)."""
+    out = [make_params(), make_params(a=2, b=5), make_params(o_del=4, e_del=2, o_ins=6, e_ins=1),
+           make_params(o_del=0, e_del=2, o_ins=1, e_ins=3), make_params(a=3, b=1, o_del=2, o_ins=3, e_ins=2)]
+    while len(out) < n:
+        m = rng.integers(-6, 7, 25).astype(np.int8)
+        m[0], m[6] = 2, 1
+        out.append(make_params(a=int(rng.integers(1, 4)), o_del=int(rng.integers(0, 8)), e_del=int(rng.integers(1, 4)),
+                               o_ins=int(rng.integers(1, 8)), e_ins=int(rng.integers(1, 4)), mat=m))
+    return out[:n]

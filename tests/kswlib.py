@@ -35,11 +35,18 @@ SEED = np.dtype([("rbeg", "<i8"), ("qbeg", "<i4"), ("len", "<i4")])
 ALNREG = np.dtype([("rb", "<i8"), ("re", "<i8"), ("qb", "<i4"), ("qe", "<i4"), ("score", "<i4"),
                    ("truesc", "<i4"), ("sub", "<i4"), ("csub", "<i4"), ("sub_n", "<i4"),
                    ("w", "<i4"), ("seedcov", "<i4"), ("secondary", "<i4"), ("hash", "<u8")])
+SW_TASK = np.dtype([("q_off", "<u8"), ("t_off", "<u8"), ("tlen", "<u4"), ("qlen", "<u2"), ("flags", "<u2"),
+                    ("xtra", "<u4"), ("rsv", "<u4")])
+SW_RES = np.dtype([("score", "<i4"), ("te", "<i4"), ("qe", "<i4"), ("score2", "<i4"), ("te2", "<i4"),
+                   ("tb", "<i4"), ("qb", "<i4"), ("rsv", "<i4")])
+KSW_XBYTE, KSW_XSTOP, KSW_XSUBO, KSW_XSTART = 0x10000, 0x20000, 0x40000, 0x80000  # reference ksw.h:6-9
+SW_FIELDS = ("score", "te", "qe", "score2", "te2", "tb", "qb")
+assert SW_TASK.itemsize == 32 and SW_RES.itemsize == 32
 assert EXT_TASK.itemsize == 32 and EXT_RES.itemsize == 24
 assert GLB_TASK.itemsize == 32 and GLB_RES.itemsize == 8
 assert PARAMS.itemsize == 64 and SEED.itemsize == 16 and ALNREG.itemsize == 64
 
-BMH_F_QREV, BMH_F_TREV, BMH_F_TPAC = 1, 2, 4
+BMH_F_QREV, BMH_F_TREV, BMH_F_TPAC, BMH_F_QCOMP = 1, 2, 4, 8
 
 
 def fill_scmat(a, b, n_score=-1):
@@ -68,6 +75,10 @@ class OrcScoring(C.Structure):
                 ("zdrop", C.c_int), ("m", C.c_int), ("mat", C.POINTER(C.c_int8))]
 
 
+class Kswr(C.Structure):  # kswr_t, reference ksw.h:14-19
+    _fields_ = [(n, C.c_int) for n in ("score", "te", "qe", "score2", "te2", "tb", "qb")]
+
+
 class OrcExtOut(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("score", "qle", "tle", "gtle", "gscore", "max_off")]
 
@@ -93,6 +104,8 @@ def load_oracle():
         lib.orc_global.restype = C.c_int
         lib.orc_extend_batch.restype = C.c_int
         lib.orc_extend_batch_pac.restype = C.c_int
+        lib.orc_align2.restype = Kswr
+        lib.orc_sw_batch.restype = C.c_int
         lib.orc_chain2aln.restype = None
         lib.orc_get_seq.restype = C.c_void_p
         lib.orc_cal_max_gap.restype = C.c_int
@@ -114,6 +127,7 @@ def load_ref_ksw():
         lib = C.CDLL(os.path.join(REF_DIR, "libksw_ref.so"))
         lib.ksw_extend2.restype = C.c_int
         lib.ksw_global2.restype = C.c_int
+        lib.ksw_align2.restype = Kswr
         _ref_ksw = lib
     return _ref_ksw
 
@@ -171,6 +185,55 @@ def orc_extend_batch(p, pool, tasks, nthreads=1, pac=None, l_pac=0):
                              pac.ctypes.data_as(C.c_void_p) if pac is not None else None, C.c_int64(l_pac),
                              tasks.ctypes.data_as(C.c_void_p), C.c_int(len(tasks)), out.ctypes.data_as(C.c_void_p),
                              C.byref(cells), C.c_int(nthreads))
+    return out, cells.value
+
+
+def sw_task_seqs(pool, t, pac=None, l_pac=0):
+    """Materialise (query, target) of one SW_TASK honouring QREV/QCOMP/TREV/TPAC."""
+    flags, ql, tl = int(t["flags"]), int(t["qlen"]), int(t["tlen"])
+    qo, to = int(t["q_off"]), int(t["t_off"])
+    q = pool[qo - ql + 1: qo + 1][::-1] if flags & BMH_F_QREV else pool[qo: qo + ql]
+    q = np.ascontiguousarray(q).copy()
+    if flags & BMH_F_QCOMP:
+        q = np.where(q < 4, 3 - q, 4).astype(np.uint8)
+    if flags & BMH_F_TPAC:
+        pos = to - np.arange(tl) if flags & BMH_F_TREV else to + np.arange(tl)
+        f = np.where(pos >= l_pac, 2 * l_pac - 1 - pos, pos)
+        b = (pac[f >> 2] >> ((~f & 3) << 1)) & 3
+        tg = np.where(pos >= l_pac, 3 - b, b).astype(np.uint8)
+    else:
+        tg = pool[to - tl + 1: to + 1][::-1] if flags & BMH_F_TREV else pool[to: to + tl]
+    return q, np.ascontiguousarray(tg).copy()
+
+
+def ref_sw_batch(p, pool, tasks, pac=None, l_pac=0):
+    """Run the compiled REFERENCE ksw_align2 (qry = NULL) on every task."""
+    lib = load_ref_ksw()
+    out = np.zeros(len(tasks), dtype=SW_RES)
+    mat = np.ascontiguousarray(p["mat"], dtype=np.int8)
+    for k, t in enumerate(tasks):
+        q, tg = sw_task_seqs(pool, t, pac, l_pac)
+        r = lib.ksw_align2(len(q), _u8p(q), len(tg), _u8p(tg), 5, mat.ctypes.data_as(C.POINTER(C.c_int8)),
+                           int(p["o_del"]), int(p["e_del"]), int(p["o_ins"]), int(p["e_ins"]), int(t["xtra"]), None)
+        out[k] = tuple(getattr(r, f) for f in SW_FIELDS) + (0,)
+    return out
+
+
+def orc_sw_batch(p, pool, tasks, nthreads=1, pac=None, l_pac=0):
+    """OUR restatement of ksw_align2 on every task; returns (results, cells).  results["rsv"] = 1 marks inputs for
+    which the reference's behaviour is undefined (byte overflow + KSW_XSTART)."""
+    lib = load_oracle()
+    tasks = np.ascontiguousarray(tasks, dtype=SW_TASK)
+    pool = np.ascontiguousarray(pool, dtype=np.uint8)
+    pp = np.ascontiguousarray(p, dtype=PARAMS)
+    if pac is not None:
+        pac = np.ascontiguousarray(pac, dtype=np.uint8)
+    out = np.zeros(len(tasks), dtype=SW_RES)
+    cells = C.c_int64(0)
+    lib.orc_sw_batch(pp.ctypes.data_as(C.c_void_p), pool.ctypes.data_as(C.c_void_p),
+                     pac.ctypes.data_as(C.c_void_p) if pac is not None else None, C.c_int64(l_pac),
+                     tasks.ctypes.data_as(C.c_void_p), C.c_int(len(tasks)), out.ctypes.data_as(C.c_void_p),
+                     C.byref(cells), C.c_int(nthreads))
     return out, cells.value
 
 

@@ -65,3 +65,16 @@ def test_oracle_reg2cigar_matches_reference_mem_reg2aln_fixture():
             assert nm == enm and fmd == emd
             n += 1
     assert n >= 2000
+
+
+def test_oracle_sw_matches_reference_fixture():
+    """orc_align2 == the reference's ksw_align2 (ksw.c:341-364) on the committed mate-rescue / fuzz vectors."""
+    g = kswlib.load_golden("sw_golden.npz")
+    pool, tasks, exp, grp, params = g["pool"], g["tasks"], g["expect"], g["group"], g["params"]
+    assert len(tasks) >= 2000 and (exp["score2"] > 0).sum() > 200 and (exp["tb"] >= 0).sum() > 500
+    for k in range(len(params)):
+        sel = np.nonzero(grp == k)[0]
+        got, _ = kswlib.orc_sw_batch(params[k], pool, tasks[sel], nthreads=4)
+        assert (got["rsv"] == 0).all()
+        for f in kswlib.SW_FIELDS:
+            assert (got[f] == exp[sel][f]).all(), f"parameter set {k}, field {f}"

@@ -1,0 +1,121 @@
+"""SURVEY.md §8(f) row 2 -- local Smith-Waterman for mate rescue / short chains on the GPU: bmh_sw_batch must return
+kswr_t field for field what the reference's ksw_align2 (ksw.c:341-364) returns, byte-mode / word-mode layout
+effects included."""
+import numpy as np
+import pytest
+
+import kswgen
+import kswlib
+from __graft_entry__ import load_package
+from test_kernel_families_gpu import _ctx_with
+
+pytestmark = pytest.mark.gpu
+
+
+def _cmp(got, want, tasks, what):
+    for f in kswlib.SW_FIELDS:
+        bad = np.nonzero(got[f] != want[f])[0]
+        assert len(bad) == 0, f"{what}, {f}: task {tasks[bad[0]]} gpu={got[bad[0]]} want={want[bad[0]]}"
+
+
+@pytest.mark.parametrize("mode", ["default", "generic"])
+def test_sw_matches_reference_fixture(mode):
+    ctx = _ctx_with({"BMH_SW_MODE": mode})
+    g = kswlib.load_golden("sw_golden.npz")
+    pool, tasks, exp, grp, params = g["pool"], g["tasks"], g["expect"], g["group"], g["params"]
+    for k in range(len(params)):
+        sel = np.nonzero(grp == k)[0]
+        ctx.set_params(params[k])
+        _cmp(ctx.sw_batch(pool, tasks[sel]), exp[sel], tasks[sel], f"{mode} set {k}")
+    ctx.close()
+
+
+@pytest.mark.parametrize("mode", ["default", "generic"])
+def test_sw_matches_oracle_materescue_and_fuzz(mode):
+    ctx = _ctx_with({"BMH_SW_MODE": mode})
+    rng = np.random.default_rng(121)
+    p = kswlib.make_params()
+    ctx.set_params(p)
+    for kw in (dict(n=3000), dict(n=1500, read_len=(30, 160), win=(20, 500), hard=True),
+               dict(n=600, read_len=(100, 400), win=(100, 900), hard=True)):
+        n = kw.pop("n")
+        pool, tasks = kswgen.gen_sw_materescue(rng, n, p, **kw)
+        want, _ = kswlib.orc_sw_batch(p, pool, tasks, nthreads=8)
+        _cmp(ctx.sw_batch(pool, tasks), want, tasks, f"{mode} materescue {kw}")
+    for p in kswgen.sw_param_sets(rng, 8):
+        ctx.set_params(p)
+        pool, tasks = kswgen.gen_sw_fuzz(rng, 500, p)
+        want, _ = kswlib.orc_sw_batch(p, pool, tasks, nthreads=8)
+        assert (want["rsv"] == 0).all()
+        _cmp(ctx.sw_batch(pool, tasks), want, tasks, f"{mode} fuzz")
+    ctx.close()
+
+
+def test_sw_target_from_resident_reference():
+    """BMH_F_TPAC: the rescue window is read straight from the 2-bit reference (what mem_matesw gets from
+    bns_get_seq, reference bwamem_pair.c:143), the mate reverse-complemented by flags (bwamem_pair.c:130-133)."""
+    from test_pac_resident_gpu import _pac_tasks  # reuses its synthetic genome builder
+    rng = np.random.default_rng(131)
+    l_pac = 60001
+    pac, _, _, _ = _pac_tasks(rng, 1, l_pac, (100, 100))
+    bases = ((pac[np.arange(l_pac) >> 2] >> ((~np.arange(l_pac) & 3) << 1)) & 3).astype(np.uint8)
+    dbl = np.concatenate([bases, (3 - bases)[::-1]])
+    p = kswlib.make_params()
+    pool_parts, tasks, off = [], [], 0
+    for _ in range(1200):
+        L = int(rng.integers(70, 151))
+        W = int(rng.integers(200, 600)) + L
+        rb = int(rng.integers(0, 2 * l_pac - W))
+        if rb < l_pac < rb + W:
+            rb = l_pac  # a window never straddles the strand boundary (bns_get_seq returns len 0 then)
+        win = dbl[rb:rb + W]
+        st = int(rng.integers(0, W - L))
+        mate = kswgen.mutate(rng, win[st:st + L], sub=0.03, ins=0.003, dele=0.003, max_indel=3)
+        if len(mate) < 20:
+            continue
+        # store the mate as the reverse complement of what is aligned; QREV|QCOMP undo it
+        stored = (3 - mate)[::-1].astype(np.uint8)
+        pool_parts.append(stored)
+        t = np.zeros((), kswlib.SW_TASK)
+        t["q_off"], t["qlen"] = off + len(stored) - 1, len(mate)
+        t["t_off"], t["tlen"] = rb, W
+        t["flags"] = kswlib.BMH_F_QREV | kswlib.BMH_F_QCOMP | kswlib.BMH_F_TPAC
+        t["xtra"] = kswgen.sw_xtra_bwa(p, len(mate))
+        tasks.append(t)
+        off += len(stored)
+    pool = np.concatenate(pool_parts + [np.zeros(16, np.uint8)])
+    tasks = np.array(tasks)
+    want, _ = kswlib.orc_sw_batch(p, pool, tasks, nthreads=8, pac=pac, l_pac=l_pac)
+    assert (want["score"] > 40).mean() > 0.8
+    ctx = _ctx_with({})
+    with pytest.raises(Exception):
+        ctx.sw_batch(pool, tasks)
+    ctx.set_pac(pac, l_pac)
+    _cmp(ctx.sw_batch(pool, tasks), want, tasks, "tpac")
+    ctx.close()
+
+
+def test_sw_refuses_what_it_cannot_do_exactly():
+    pkg = load_package()
+    ctx = _ctx_with({})
+    rng = np.random.default_rng(141)
+    p = kswlib.make_params(o_ins=0)
+    ctx.set_params(p)
+    pool, tasks = kswgen.gen_sw_materescue(rng, 10, p)
+    with pytest.raises(pkg.BmhError):  # o_ins == 0: the reference's lazy-F loop is not a closed recurrence
+        ctx.sw_batch(pool, tasks)
+    p = kswlib.make_params(a=3, b=6)
+    ctx.set_params(p)
+    q = kswgen.rand_seq(rng, 100)
+    pool = np.concatenate([q, q, np.zeros(8, np.uint8)])
+    t = np.zeros(1, kswlib.SW_TASK)
+    t["q_off"], t["t_off"], t["qlen"], t["tlen"] = 0, 100, 100, 100
+    t["xtra"] = kswlib.KSW_XBYTE | kswlib.KSW_XSUBO | 19  # byte mode overflows: score 255, nothing else (ksw.c:198-200)
+    want, _ = kswlib.orc_sw_batch(p, pool, t)
+    assert want["score"][0] == 255 and want["qe"][0] == -1
+    _cmp(ctx.sw_batch(pool, t), want, t, "byte overflow")
+    t["xtra"] |= kswlib.KSW_XSTART  # ... and asking for start positions on top of it is undefined in the reference
+    assert kswlib.orc_sw_batch(p, pool, t)[0]["rsv"][0] == 1
+    with pytest.raises(pkg.BmhError):
+        ctx.sw_batch(pool, t)
+    ctx.close()

@@ -13,7 +13,9 @@ compiled reference returns:
                        for several parameter sets (default, -w 10, -w 20 -d 20, asymmetric gaps, -A 2)
 
 The fixtures are DATA (inputs and expected outputs); no reference source is stored.
-Usage: python tools/make_golden.py
+  sw_golden.npz        ksw_align2    (reference ksw.c:341)   mate-rescue shaped tasks + fuzz, kswr_t results
+
+Usage: python tools/make_golden.py [ext|glb|chain2aln|cigar|sw ...]
 """
 import os
 import sys
@@ -85,6 +87,23 @@ def make_glb():
     np.savez_compressed(os.path.join(OUT, "glb_golden.npz"), pool=pool, tasks=tasks, expect=exp, group=gidx,
                         params=params, cigar=np.concatenate(cig_all))
     print("glb_golden:", len(tasks), "tasks")
+
+
+def make_sw():
+    """ksw_align2 (reference ksw.c:341-364): mate-rescue shaped tasks + function-level fuzz, several parameter sets."""
+    rng = np.random.default_rng(20261007)
+    groups = []
+    d = kswlib.make_params()
+    pool, t = kswgen.gen_sw_materescue(rng, 300, d)
+    groups.append((d, pool, t, kswlib.ref_sw_batch(d, pool, t)))
+    pool, t = kswgen.gen_sw_materescue(rng, 250, d, read_len=(60, 260), win=(50, 500), hard=True)
+    groups.append((d, pool, t, kswlib.ref_sw_batch(d, pool, t)))
+    for p in kswgen.sw_param_sets(rng, 10):
+        pool, t = kswgen.gen_sw_fuzz(rng, 150, p)
+        groups.append((p, pool, t, kswlib.ref_sw_batch(p, pool, t)))
+    pool, tasks, exp, gidx, params = concat_groups(groups, kswlib.SW_TASK)
+    np.savez_compressed(os.path.join(OUT, "sw_golden.npz"), pool=pool, tasks=tasks, expect=exp, group=gidx, params=params)
+    print("sw_golden:", len(tasks), "tasks,", len(params), "parameter sets")
 
 
 def sim_reads(rng, ref, n, lens, hard):
@@ -194,9 +213,8 @@ def make_cigar():
 if __name__ == "__main__":
     assert kswlib.have_ref() and reflib.have_ref_bwa(), "build oracle/_ref first (make -C oracle)"
     os.makedirs(OUT, exist_ok=True)
-    make_ext()
-    make_glb()
-    make_chain2aln()
-    make_cigar()
+    makers = {"ext": make_ext, "glb": make_glb, "chain2aln": make_chain2aln, "cigar": make_cigar, "sw": make_sw}
+    for name in (sys.argv[1:] or list(makers)):  # e.g. `make_golden.py sw` regenerates one fixture only
+        makers[name]()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)), "bytes")
