@@ -135,7 +135,7 @@ int bmh_ctx_destroy(bmh_ctx_t *ctx)
 	(void)hipSetDevice(ctx->device);
 	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 	free_buf(ctx->d_pool), free_buf(ctx->d_tasks), free_buf(ctx->d_res), free_buf(ctx->d_order);
-	free_buf(ctx->d_cigar), free_buf(ctx->d_scratch), free_buf(ctx->d_bins), free_buf(ctx->d_zslab), free_buf(ctx->d_sw);
+	free_buf(ctx->d_cigar), free_buf(ctx->d_scratch), free_buf(ctx->d_bins), free_buf(ctx->d_zslab), free_buf(ctx->d_sw), free_buf(ctx->d_swrm);
 	pac_release(ctx);
 	if (ctx->d_err) (void)hipFree(ctx->d_err);
 	if (ctx->h_err) (void)hipHostFree(ctx->h_err);

@@ -24,6 +24,7 @@ struct bmh_ctx {
 	// device workspaces of the host-buffer entry points
 	DevBuf d_pool, d_tasks, d_res, d_order, d_cigar, d_scratch;
 	const uint8_t *h_pac = nullptr; // host identity of the shared device copy of the 2-bit reference (bmh_ctx_set_pac)
+	DevBuf d_swrm;  // per-wave row maxima of the register Smith-Waterman kernels
 	DevBuf d_sw;    // row / row-maximum slabs of the local Smith-Waterman kernels
 	DevBuf d_zslab; // direction words of the lane-per-task global kernels, one slab per resident wave
 	int glb_mode = 0; // 0 lane-per-task global kernels, 1 one wave per task only (env BMH_GLB_MODE=wave)
@@ -80,6 +81,9 @@ int launch_extend_lanex(bmh_ctx *ctx, int lpt, const uint8_t *d_pool, const bmh_
                         bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, int min_count);
 int launch_sw(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks, int64_t n, bmh_sw_result_t *d_res,
               int qcap, int tcap);
+int launch_sw_lane(bmh_ctx *ctx, int b, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks, int64_t n,
+                   bmh_sw_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, uint16_t *d_rm, int rows_cap,
+                   int grid, int pass2);
 int launch_sw_generic(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks, int64_t n,
                       bmh_sw_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, int qcap, int tcap);
 int launch_extend_lane(bmh_ctx *ctx, int c, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,

@@ -18,6 +18,51 @@ __global__ void sw_caps_kernel(const bmh_sw_task_t *__restrict__ tasks, long lon
 	if ((threadIdx.x & 63) == 0) atomicMax(&caps[0], q), atomicMax(&caps[1], t);
 }
 
+// ---- device-side routing: a counting sort by (kernel, query length, target length), like the extension dispatcher
+//   bin 0: byte mode, cannot overflow, padded query <= 80 columns   sw_lane_kernel<40>
+//   bin 1: ... <= 160 columns                                        sw_lane_kernel<80>
+//   bin 2: everything else                                           sw_generic_kernel (both passes)
+//   bin 5: nothing to do (second pass not wanted)
+__device__ __forceinline__ int sw_bin_of(const DevParams &P, int qlen, uint32_t xtra, int mode)
+{
+	if (mode == 1 || !(xtra & BMH_SW_XBYTE) || qlen < 1 || qlen * P.max_mat + P.sw_shift >= 255) return 2;
+	const int Qp = ((qlen + 15) >> 4) * 16;
+	return Qp <= 80 ? 0 : Qp <= 160 ? 1 : 2;
+}
+
+constexpr int kSwSortThreads = 256;
+__global__ __launch_bounds__(kSwSortThreads) void sw_hist_kernel(const bmh_sw_task_t *__restrict__ tasks, long long n,
+                                                                 const bmh_sw_result_t *__restrict__ res, DevParams P,
+                                                                 uint32_t *__restrict__ hist,
+                                                                 uint16_t *__restrict__ binkey, int mode, int pass2)
+{
+	__shared__ uint32_t lh[kExtBins * kSortKeysHost];
+	for (int t = threadIdx.x; t < kExtBins * kSortKeysHost; t += kSwSortThreads) lh[t] = 0;
+	__syncthreads();
+	const long long chunk = (n + gridDim.x - 1) / gridDim.x, lo = chunk * blockIdx.x, hi = min(lo + chunk, n);
+	for (long long k = lo + threadIdx.x; k < hi; k += kSwSortThreads) {
+		const uint32_t xtra = tasks[k].xtra;
+		int qlen = tasks[k].qlen, rows = (int)min(tasks[k].tlen, 0xffffu);
+		int bin = sw_bin_of(P, qlen, xtra, mode);
+		if (pass2) { // ksw.c:354: only where start positions are wanted and the first pass reached the threshold
+			const int score = res[k].score;
+			const bool second = bin < 2 && (xtra & BMH_SW_XSTART) && !((xtra & BMH_SW_XSUBO) && score < (int)(xtra & 0xffff)) &&
+			                    res[k].qe >= 0;
+			qlen = res[k].qe + 1;
+			bin = second ? sw_bin_of(P, qlen, xtra, mode) : 5;
+			rows = min(rows, 2 * qlen + 16); // the reversed pass stops once the score is reached
+		}
+		// lanes of a wave must share ceil(qlen/16) and should share qlen (uniform padding) and the row count
+		const int key = bin >= 2 ? 0 : (min(qlen, 255) << 3) | min(rows >> 7, 7);
+		const int bk = bin * kSortKeysHost + key;
+		binkey[k] = (uint16_t)bk;
+		atomicAdd(&lh[bk], 1u);
+	}
+	__syncthreads();
+	for (int t = threadIdx.x; t < kExtBins * kSortKeysHost; t += kSwSortThreads)
+		if (lh[t]) atomicAdd(&hist[t], lh[t]);
+}
+
 int launch_sw(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks, int64_t n, bmh_sw_result_t *d_res,
               int qcap, int tcap)
 {
@@ -42,8 +87,30 @@ int launch_sw(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks,
 		qcap = h[0], tcap = h[1];
 	}
 	qcap = std::max(qcap, 1) + 16, tcap = std::max(tcap, 1);
+	if (ctx->params.o_del > 255 || ctx->params.e_del > 255 || ctx->params.o_ins > 255 || ctx->params.e_ins > 255) {
+		ctx->last_error = "the Smith-Waterman kernels need gap penalties below 256";
+		return BMH_E_RANGE;
+	}
+	const int mode = ctx->sw_mode;
+	const size_t N = (size_t)n;
+	uint32_t *counts, *lists;
+	long long cg = std::min<long long>((n + 1023) / 1024, 512);
+	// per-wave slab of row maxima for the second-best score (ksw.c:181-189): [block][row][lane] u16
+	const int grid = (int)std::min<long long>((n + 63) / 64, 4096);
+	if ((rc = ensure(ctx, ctx->d_swrm, (size_t)grid * (size_t)tcap * 128))) return rc;
+	uint16_t *d_rm = (uint16_t *)ctx->d_swrm.p;
 	if (ctx->timing) BMH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-	if ((rc = launch_sw_generic(ctx, d_pool, d_tasks, n, d_res, nullptr, nullptr, qcap, tcap))) return rc;
+	for (int pass2 = 0; pass2 < 2; ++pass2) {
+		if ((rc = sort_tasks_begin(ctx, n, &counts, &lists))) return rc;
+		uint32_t *hist = counts + 16;
+		uint16_t *binkey = (uint16_t *)(hist + (size_t)kExtBins * kSortKeysHost);
+		hipLaunchKernelGGL(sw_hist_kernel, dim3((unsigned)cg), dim3(kSwSortThreads), 0, ctx->stream, d_tasks, (long long)n,
+		                   d_res, ctx->dev, hist, binkey, mode, pass2);
+		if ((rc = sort_tasks_finish(ctx, n, nullptr, (unsigned)cg))) return rc;
+		if ((rc = launch_sw_lane(ctx, 40, d_pool, d_tasks, n, d_res, lists, counts, d_rm, tcap, grid, pass2))) return rc;
+		if ((rc = launch_sw_lane(ctx, 80, d_pool, d_tasks, n, d_res, lists + N, counts + 1, d_rm, tcap, grid, pass2))) return rc;
+		if (!pass2 && (rc = launch_sw_generic(ctx, d_pool, d_tasks, n, d_res, lists + 2 * N, counts + 2, qcap, tcap))) return rc;
+	}
 	if (ctx->timing) {
 		BMH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
 		ctx->ev_valid = true;
