@@ -81,9 +81,9 @@ int launch_extend_lanex(bmh_ctx *ctx, int lpt, const uint8_t *d_pool, const bmh_
                         bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, int min_count);
 int launch_sw(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks, int64_t n, bmh_sw_result_t *d_res,
               int qcap, int tcap);
-int launch_sw_lane(bmh_ctx *ctx, int b, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks, int64_t n,
+int launch_sw_lane(bmh_ctx *ctx, int b, bool corr, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks, int64_t n,
                    bmh_sw_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, uint16_t *d_rm, int rows_cap,
-                   int grid, int pass2);
+                   int grid, int pass2, uint32_t *d_next);
 int launch_sw_generic(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks, int64_t n,
                       bmh_sw_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, int qcap, int tcap);
 int launch_extend_lane(bmh_ctx *ctx, int c, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,

@@ -22,6 +22,7 @@ __global__ void sw_caps_kernel(const bmh_sw_task_t *__restrict__ tasks, long lon
 //   bin 0: byte mode, cannot overflow, padded query <= 80 columns   sw_lane_kernel<40>
 //   bin 1: ... <= 160 columns                                        sw_lane_kernel<80>
 //   bin 2: everything else                                           sw_generic_kernel (both passes)
+//   bin 3, 4: like 0, 1 for queries holding an N                     sw_lane_kernel<.., CORR>
 //   bin 5: nothing to do (second pass not wanted)
 __device__ __forceinline__ int sw_bin_of(const DevParams &P, int qlen, uint32_t xtra, int mode)
 {
@@ -34,7 +35,8 @@ constexpr int kSwSortThreads = 256;
 __global__ __launch_bounds__(kSwSortThreads) void sw_hist_kernel(const bmh_sw_task_t *__restrict__ tasks, long long n,
                                                                  const bmh_sw_result_t *__restrict__ res, DevParams P,
                                                                  uint32_t *__restrict__ hist,
-                                                                 uint16_t *__restrict__ binkey, int mode, int pass2)
+                                                                 uint16_t *__restrict__ binkey, int mode, int pass2,
+                                                                 const uint8_t *__restrict__ pool)
 {
 	__shared__ uint32_t lh[kExtBins * kSortKeysHost];
 	for (int t = threadIdx.x; t < kExtBins * kSortKeysHost; t += kSwSortThreads) lh[t] = 0;
@@ -44,16 +46,24 @@ __global__ __launch_bounds__(kSwSortThreads) void sw_hist_kernel(const bmh_sw_ta
 		const uint32_t xtra = tasks[k].xtra;
 		int qlen = tasks[k].qlen, rows = (int)min(tasks[k].tlen, 0xffffu);
 		int bin = sw_bin_of(P, qlen, xtra, mode);
+		bool has_n = false;
+		if (!pass2 && bin < 2) { // an N anywhere in the query sends the task to the correcting instantiation
+			const uint64_t q0 = tasks[k].q_off;
+			const bool rev = tasks[k].flags & BMH_F_QREV;
+			for (int x = 0; x < qlen; ++x) has_n |= (rev ? pool[q0 - x] : pool[q0 + x]) > 3;
+		}
 		if (pass2) { // ksw.c:354: only where start positions are wanted and the first pass reached the threshold
 			const int score = res[k].score;
 			const bool second = bin < 2 && (xtra & BMH_SW_XSTART) && !((xtra & BMH_SW_XSUBO) && score < (int)(xtra & 0xffff)) &&
 			                    res[k].qe >= 0;
 			qlen = res[k].qe + 1;
 			bin = second ? sw_bin_of(P, qlen, xtra, mode) : 5;
+			has_n = res[k].rsv != 0;
 			rows = min(rows, 2 * qlen + 16); // the reversed pass stops once the score is reached
 		}
 		// lanes of a wave must share ceil(qlen/16) and should share qlen (uniform padding) and the row count
 		const int key = bin >= 2 ? 0 : (min(qlen, 255) << 3) | min(rows >> 7, 7);
+		if (bin < 2 && has_n) bin += 3;
 		const int bk = bin * kSortKeysHost + key;
 		binkey[k] = (uint16_t)bk;
 		atomicAdd(&lh[bk], 1u);
@@ -96,8 +106,8 @@ int launch_sw(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks,
 	uint32_t *counts, *lists;
 	long long cg = std::min<long long>((n + 1023) / 1024, 512);
 	// per-wave slab of row maxima for the second-best score (ksw.c:181-189): [block][row][lane] u16
-	const int grid = (int)std::min<long long>((n + 63) / 64, 4096);
-	if ((rc = ensure(ctx, ctx->d_swrm, (size_t)grid * (size_t)tcap * 128))) return rc;
+	const int grid = (int)std::min<long long>((n + 63) / 64, 2048 * ctx->grid_mult); // resident waves: 256 CUs x 4 SIMDs x 2
+	if ((rc = ensure(ctx, ctx->d_swrm, (size_t)grid * ((size_t)tcap * 128 + 2048)))) return rc; // + kSwTableBytes per wave
 	uint16_t *d_rm = (uint16_t *)ctx->d_swrm.p;
 	if (ctx->timing) BMH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
 	for (int pass2 = 0; pass2 < 2; ++pass2) {
@@ -105,10 +115,12 @@ int launch_sw(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks,
 		uint32_t *hist = counts + 16;
 		uint16_t *binkey = (uint16_t *)(hist + (size_t)kExtBins * kSortKeysHost);
 		hipLaunchKernelGGL(sw_hist_kernel, dim3((unsigned)cg), dim3(kSwSortThreads), 0, ctx->stream, d_tasks, (long long)n,
-		                   d_res, ctx->dev, hist, binkey, mode, pass2);
+		                   d_res, ctx->dev, hist, binkey, mode, pass2, d_pool);
 		if ((rc = sort_tasks_finish(ctx, n, nullptr, (unsigned)cg))) return rc;
-		if ((rc = launch_sw_lane(ctx, 40, d_pool, d_tasks, n, d_res, lists, counts, d_rm, tcap, grid, pass2))) return rc;
-		if ((rc = launch_sw_lane(ctx, 80, d_pool, d_tasks, n, d_res, lists + N, counts + 1, d_rm, tcap, grid, pass2))) return rc;
+		if ((rc = launch_sw_lane(ctx, 80, false, d_pool, d_tasks, n, d_res, lists + N, counts + 1, d_rm, tcap, grid, pass2, counts + 9))) return rc;
+		if ((rc = launch_sw_lane(ctx, 80, true, d_pool, d_tasks, n, d_res, lists + 4 * N, counts + 4, d_rm, tcap, grid, pass2, counts + 12))) return rc;
+		if ((rc = launch_sw_lane(ctx, 40, false, d_pool, d_tasks, n, d_res, lists, counts, d_rm, tcap, grid, pass2, counts + 8))) return rc;
+		if ((rc = launch_sw_lane(ctx, 40, true, d_pool, d_tasks, n, d_res, lists + 3 * N, counts + 3, d_rm, tcap, grid, pass2, counts + 11))) return rc;
 		if (!pass2 && (rc = launch_sw_generic(ctx, d_pool, d_tasks, n, d_res, lists + 2 * N, counts + 2, qcap, tcap))) return rc;
 	}
 	if (ctx->timing) {

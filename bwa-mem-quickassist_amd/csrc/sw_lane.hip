@@ -20,6 +20,7 @@
 //     a boundary runs its groups one after the other.
 // Pass 2 (start positions, ksw.c:355-361) is the same kernel over the reversed prefixes with KSW_XSTOP|score.
 #include <algorithm>
+#include <type_traits>
 
 #include "bmh_ctx.h"
 #include "bmh_device.h"
@@ -27,6 +28,7 @@
 
 namespace bmh {
 
+constexpr int kSwTableBytes = 2048; // >= 16 * B
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ us2 as_us2(uint32_t x) { return __builtin_bit_cast(us2, x); }
 __device__ __forceinline__ uint32_t as_u32(us2 x) { return __builtin_bit_cast(uint32_t, x); }
@@ -35,6 +37,16 @@ __device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b) { return as_
 __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return as_u32(__builtin_elementwise_max(as_us2(a), as_us2(b))); }
 __device__ __forceinline__ uint32_t pk_shr(uint32_t a, int k) { return as_u32(as_us2(a) >> (us2)((unsigned short)k)); }
 __device__ __forceinline__ uint32_t pk_mul(uint32_t a, uint32_t b) { return as_u32(as_us2(a) * as_us2(b)); }
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N-1>{})
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+	if constexpr (I < N) {
+		f(std::integral_constant<int, I>{});
+		static_for<N, I + 1>(f);
+	}
+}
 
 struct SwLaneSeq { // where a lane's sequences come from
 	const uint8_t *pool;
@@ -58,25 +70,28 @@ __device__ __forceinline__ int swl_tbase(const SwLaneSeq &s, const DevParams &P,
 	return c > 4 ? 4 : c;
 }
 
-template <int B>
+// SYM: o_del == o_ins, H-o is shared by the E and F updates.  CORR: queries with N (and waves whose lanes differ in
+// length) -- such columns take a per-lane score correction; the dispatcher keeps those tasks apart, and the plain
+// instantiation groups its lanes by exact query length, so that padding is wave-uniform and needs no correction.
+template <int B, bool SYM, bool CORR>
 __global__ __launch_bounds__(64, B <= 40 ? 3 : 2) void sw_lane_kernel(const uint8_t *__restrict__ pool,
                                                                     const bmh_sw_task_t *__restrict__ tasks,
                                                                     const uint32_t *__restrict__ order,
                                                                     const uint32_t *__restrict__ count, long long n,
                                                                     bmh_sw_result_t *out, DevParams P,
                                                                     uint16_t *__restrict__ rmslab, int rows_cap,
-                                                                    int pass2, int *__restrict__ err_flag)
+                                                                    int pass2, int *__restrict__ err_flag,
+                                                                    uint32_t *__restrict__ next_chunk)
 {
 	constexpr int NB = B / 8, NG = (B + 15) / 16;
 	__shared__ uint2 srow[8];              // [t] = {biased scores of target base t against A,C,G,T; against N}
-	__shared__ uint4 xt[B];                // per column pair {SH_j, Xseg_{j+1}, Xfull_{j+1}, -}
 	__shared__ uint32_t wl[(B / 2) * 64]; // v_perm selectors, two column pairs per dword, [word][lane]
+	__shared__ uint32_t ml[CORR ? 2 * ((B + 15) / 16) * 64 : 64]; // N / lane-specific padding bits per 16 columns, [2*g16+kind][lane]
 	const int lane = threadIdx.x;
 	const uint32_t shift = (uint32_t)P.sw_shift;
 	const uint32_t odel = (uint32_t)P.o_del << 8 | (uint32_t)P.o_del << 24, edel = (uint32_t)P.e_del << 8 | (uint32_t)P.e_del << 24;
 	const uint32_t oins = (uint32_t)P.o_ins << 8 | (uint32_t)P.o_ins << 24;
-	const uint32_t shpair = shift << 8 | shift << 24;
-	const bool sym = P.o_del == P.o_ins;
+	const uint32_t shpair = shift << 8 | shift << 24, einspair = (uint32_t)P.e_ins << 8 | (uint32_t)P.e_ins << 24;
 
 	if (lane < 8) {
 		uint32_t lo = 0, nn = 0;
@@ -87,9 +102,20 @@ __global__ __launch_bounds__(64, B <= 40 ? 3 : 2) void sw_lane_kernel(const uint
 		srow[lane] = make_uint2(lo, nn);
 	}
 	const long long cnt = count ? (long long)*count : n;
-	uint16_t *rm = rmslab ? rmslab + (size_t)blockIdx.x * (size_t)rows_cap * 64 + lane : nullptr;
+	// this wave's slab: the wave-uniform per-column subtrahend table {SH_j, Xseg_{j+1}} (written once per
+	// group, then read back through the SCALAR cache: the values arrive in SGPRs, cost no VALU or LDS slot and no
+	// VGPR), followed by the per-row maxima [row][lane]
+	uint8_t *slab = (uint8_t *)rmslab + (size_t)blockIdx.x * ((size_t)rows_cap * 128 + kSwTableBytes);
+	uint2 *xt = (uint2 *)slab;
+	uint16_t *rm = (uint16_t *)(slab + kSwTableBytes) + lane;
 
-	for (long long c0 = (long long)blockIdx.x * 64; c0 < cnt; c0 += (long long)gridDim.x * 64) {
+	// chunks of 64 tasks are handed out dynamically (most expensive first): waves that drew short targets come back
+	// for more instead of idling behind a static stride
+	for (;;) {
+		uint32_t ch = 0;
+		if (lane == 0) ch = atomicAdd(next_chunk, 1u);
+		const long long c0 = (long long)__builtin_amdgcn_readfirstlane(ch) * 64;
+		if (c0 >= cnt) break;
 		const bool valid = c0 + lane < cnt;
 		const long long pos = cnt - 1 - (valid ? c0 + lane : c0); // long queries / long targets first
 		const uint32_t idx = order ? order[pos] : (uint32_t)pos;
@@ -110,7 +136,7 @@ __global__ __launch_bounds__(64, B <= 40 ? 3 : 2) void sw_lane_kernel(const uint
 			pscore = pr.score, pte = pr.te, pqe = pr.qe;
 			qlen = pqe + 1, seq.qfold = pqe, seq.tfold = pte, minsc = 0x10000, endsc = pscore;
 		}
-		const bool want_rm = !pass2 && (xtra & BMH_SW_XSUBO) && rm != nullptr;
+		const bool want_rm = !pass2 && (xtra & BMH_SW_XSUBO);
 		// the dispatcher only sends byte-mode tasks that cannot overflow and fit the register file
 		const bool bad = valid && (qlen < 1 || ((qlen + 15) >> 4) * 16 > 2 * B || !(xtra & BMH_SW_XBYTE) || qlen * P.max_mat + (int)shift >= 255 || tlen > rows_cap);
 		if (bad) atomicExch(err_flag, BMH_E_RANGE);
@@ -121,18 +147,16 @@ __global__ __launch_bounds__(64, B <= 40 ? 3 : 2) void sw_lane_kernel(const uint
 		while (__builtin_amdgcn_ballot_w64(pending) != 0) {
 			const int first = __builtin_ctzll(__builtin_amdgcn_ballot_w64(pending));
 			const int g = __builtin_amdgcn_readlane(slen, first), qlu = __builtin_amdgcn_readlane(qlen, first);
-			const bool act = pending && slen == g;
+			const bool act = pending && slen == g && (CORR || qlen == qlu);
 			pending = pending && !act;
 			const int Qp = g * 16;
-			const int Bs = min(B, ((Qp + 1) / 2 + 7) & ~7), nb = Bs / 8; // wave-uniform
+			const int Bs = Qp / 2, nb = __builtin_amdgcn_readfirstlane(g); // 8 columns per block: Q = 16*slen splits evenly
 			const bool uni_q = __builtin_amdgcn_ballot_w64(act && qlen != qlu) == 0; // padding then is wave-uniform too
 			__syncthreads();
-			for (int jj = lane; jj < B; jj += 64) {
+			for (int jj = lane; jj < B + 8; jj += 64) { // (entries past Bs are never used, only prefetched)
 				auto SH = [&](int c) { return c >= Qp ? 0xffffu : (uni_q && c >= qlu ? 0u : shift << 8); };
 				auto XS = [&](int c) { return (c >= Qp || c % g == 0) ? 0xffffu : (uint32_t)P.e_ins << 8; };
-				auto XF = [&](int c) { return c >= Qp ? 0xffffu : (uint32_t)P.e_ins << 8; };
-				xt[jj] = make_uint4(SH(jj) | SH(Bs + jj) << 16, XS(jj + 1) | XS(Bs + jj + 1) << 16,
-				                    XF(jj + 1) | XF(Bs + jj + 1) << 16, 0u);
+				xt[jj] = make_uint2(SH(jj) | SH(Bs + jj) << 16, XS(jj + 1) | XS(Bs + jj + 1) << 16);
 			}
 			uint32_t MN[NG], MP[NG]; // per 16 columns: bit k = column is N / lane-specific padding (A low half, B high half)
 #pragma unroll
@@ -148,18 +172,26 @@ __global__ __launch_bounds__(64, B <= 40 ? 3 : 2) void sw_lane_kernel(const uint
 						const int qa = ca < qlen ? swl_qbase(seq, ca) : (ca < Qp ? 5 : 6);
 						const int qb = cb < qlen ? swl_qbase(seq, cb) : (cb < Qp ? 5 : 6);
 						word |= (uint32_t)(qa < 4 ? qa : 0x0c) << (16 * k) | (uint32_t)(qb < 4 ? 4 + qb : 0x0c) << (16 * k + 8);
-						MN[jj / 16] |= (uint32_t)(qa == 4) << (jj % 16) | (uint32_t)(qb == 4) << (16 + jj % 16);
-						MP[jj / 16] |= (uint32_t)(qa == 5 && !uni_q) << (jj % 16) | (uint32_t)(qb == 5 && !uni_q) << (16 + jj % 16);
+						if (CORR) {
+							MN[jj / 16] |= (uint32_t)(qa == 4) << (jj % 16) | (uint32_t)(qb == 4) << (16 + jj % 16);
+							MP[jj / 16] |= (uint32_t)(qa == 5 && !uni_q) << (jj % 16) | (uint32_t)(qb == 5 && !uni_q) << (16 + jj % 16);
+						}
 					}
 				}
 				wl[w * 64 + lane] = word;
 			}
+			__threadfence();                 // the table is in L2 ...
+			__builtin_amdgcn_s_dcache_inv(); // ... and no stale copy of it in the scalar cache
 			uint32_t bflag = 0; // blocks in which some lane has a corrected column
 #pragma unroll
 			for (int b = 0; b < NB; ++b) {
 				const uint32_t m = (MN[b / 2] | MP[b / 2]) & (0x00ff00ffu << (8 * (b & 1)));
 				bflag |= (uint32_t)(__builtin_amdgcn_ballot_w64(m != 0) != 0) << b;
 			}
+#pragma unroll
+			for (int v = 0; v < NG; ++v)
+				if (CORR) ml[(2 * v) * 64 + lane] = MN[v], ml[(2 * v + 1) * 64 + lane] = MP[v];
+			bflag = __builtin_amdgcn_readfirstlane(bflag);
 			__syncthreads();
 
 			uint32_t H[B], E[B];
@@ -171,7 +203,9 @@ __global__ __launch_bounds__(64, B <= 40 ? 3 : 2) void sw_lane_kernel(const uint
 			uint2 rB = make_uint2(0u, 0u);
 			int tn = alive ? swl_tbase(seq, P, 0) : 4;
 			uint32_t K = 0x0c0c0c0cu;
-			int woff = lane, xoff = 0;
+			int woff = lane;
+			typedef const uint32_t __attribute__((address_space(4))) *sw_ctab_t;
+			sw_ctab_t xc = (sw_ctab_t)(uintptr_t)xt;
 
 			for (int s = 0; __builtin_amdgcn_ballot_w64(alive) != 0; ++s) {
 				const uint2 rA = srow[tn];
@@ -179,41 +213,50 @@ __global__ __launch_bounds__(64, B <= 40 ? 3 : 2) void sw_lane_kernel(const uint
 				if (alive && s + 1 < tlen) tn = swl_tbase(seq, P, s + 1);
 				const uint32_t plo = rA.x, phi = rB.x;
 				const uint32_t vN = rA.y << 8 | rB.y << 24;
-				asm volatile("" : "+v"(K), "+v"(woff), "+v"(xoff)); // keeps the row-invariant selector work inside the row loop
-#pragma unroll
-				for (int v = 0; v < NG; ++v) asm volatile("" : "+v"(MN[v]), "+v"(MP[v]));
-				uint32_t hd = hdB << 16, fs = fsB << 16, ff = ffB << 16, key = 0;
+				asm volatile("" : "+v"(K), "+v"(woff), "+s"(xc)); // keeps the row-invariant selector work inside the row loop
+				uint32_t fs = fsB << 16, ff = ffB << 16, key = 0, hlast = hdB << 16;
 #pragma unroll
 				for (int b = 0; b < NB; ++b) {
 					if (b >= nb) continue;
-					const bool flagged = (bflag >> b) & 1;
+					{
+						const bool flagged = CORR && ((bflag >> b) & 1);
+						// S'(A) << 8 | S'(B) << 24 of column pair c of the block: one v_perm over {row s scores, row s-1 scores}
+						auto subst = [&](int c) {
+							const uint32_t sel = __builtin_amdgcn_perm(wl[(4 * b + c / 2) * 64 + woff], K, (c & 1) ? 0x07000600u : 0x05000400u);
+							uint32_t sp = __builtin_amdgcn_perm(phi, plo, sel);
+							if (CORR && flagged) { // N columns score mat[t][4]; padding the other lanes do not share scores 0
+								const int jj = 8 * b + c;
+								const uint32_t xn = pk_shr(ml[(2 * (jj / 16)) * 64 + woff], jj % 16) & 0x00010001u;
+								const uint32_t xp = pk_shr(ml[(2 * (jj / 16) + 1) * 64 + woff], jj % 16) & 0x00010001u;
+								sp += pk_mul(xn, vN) + pk_mul(xp, shpair);
+							}
+							return sp;
+						};
+						// a = H(i-1,j-1) + S' of the column about to be computed; inside a block it is formed while the left
+						// neighbour still holds its previous-row value, so that the new H is written in place; hlast carries
+						// that value across block boundaries and, at the end, over to half B
+						uint32_t a = pk_adds(hlast, subst(0));
 #pragma unroll
-					for (int c = 0; c < 8; ++c) {
-						const int jj = 8 * b + c;
-						const uint4 x = xt[jj + xoff];
-						const uint32_t wsel = wl[(jj / 2) * 64 + woff];
-						const uint32_t sel = __builtin_amdgcn_perm(wsel, K, (jj & 1) ? 0x07000600u : 0x05000400u);
-						uint32_t sp = __builtin_amdgcn_perm(phi, plo, sel); // S'(A) << 8 | S'(B) << 24
-						if (flagged) {
-							const uint32_t xn = pk_shr(MN[jj / 16], jj % 16) & 0x00010001u;
-							const uint32_t xp = pk_shr(MP[jj / 16], jj % 16) & 0x00010001u;
-							sp += pk_mul(xn, vN) + pk_mul(xp, shpair);
+						for (int c = 0; c < 8; ++c) {
+							const int jj = 8 * b + c;
+							const uint32_t xsh = xc[2 * jj], xseg = xc[2 * jj + 1];
+							const uint32_t m = pk_subs(a, xsh);                  // ksw.c:149-150
+							const uint32_t hp = pk_max(pk_max(m, E[jj]), fs);          // ksw.c:151-153
+							const uint32_t h = pk_max(hp, ff);                          // lazy F, ksw.c:165-176
+							const uint32_t tag = (uint32_t)(255 - jj) * 0x00010001u;
+							key = pk_max(key, h | tag);
+							if (c < 7) a = pk_adds(H[jj], subst(c + 1));
+							else hlast = H[jj];
+							H[jj] = h;
+							const uint32_t t1 = pk_subs(hp, odel);
+							E[jj] = pk_subs(pk_max(E[jj], t1), edel);                   // ksw.c:155-158
+							const uint32_t t2 = SYM ? t1 : pk_subs(hp, oins);
+							fs = pk_subs(pk_max(fs, t2), xseg);                   // ksw.c:160-162; 0xffff restarts a segment
+							ff = pk_subs(pk_max(ff, t2), einspair);
 						}
-						const uint32_t m = pk_subs(pk_adds(hd, sp), x.x);          // ksw.c:149-150
-						const uint32_t hp = pk_max(pk_max(m, E[jj]), fs);          // ksw.c:151-153
-						const uint32_t h = pk_max(hp, ff);                          // lazy F, ksw.c:165-176
-						const uint32_t tag = (uint32_t)(255 - jj) * 0x00010001u;
-						key = pk_max(key, h | tag);
-						hd = H[jj];
-						H[jj] = h;
-						const uint32_t t1 = pk_subs(hp, odel);
-						E[jj] = pk_subs(pk_max(E[jj], t1), edel);                   // ksw.c:155-158
-						const uint32_t t2 = sym ? t1 : pk_subs(hp, oins);
-						fs = pk_subs(pk_max(fs, t2), x.y);                          // ksw.c:160-162; 0xffff restarts a segment
-						ff = pk_subs(pk_max(ff, t2), x.z);
 					}
 				}
-				hdB = hd & 0xffff, fsB = fs & 0xffff, ffB = ff & 0xffff;
+				hdB = hlast & 0xffff, fsB = fs & 0xffff, ffB = ff & 0xffff;
 				rB = rA;
 				const uint32_t kA = prevKA, kB = key >> 16;
 				prevKA = key & 0xffff;
@@ -255,7 +298,7 @@ __global__ __launch_bounds__(64, B <= 40 ? 3 : 2) void sw_lane_kernel(const uint
 			if (valid) {
 				bmh_sw_result_t res;
 				res.score = bad ? INT32_MIN : r_score, res.te = r_te, res.qe = r_qe, res.score2 = s2, res.te2 = t2;
-				res.tb = -1, res.qb = -1, res.rsv = 0;
+				res.tb = -1, res.qb = -1, res.rsv = CORR; // tells the second pass's routing that the query holds an N
 				out[idx] = res;
 			}
 		} else if (valid && !bad && r_score == pscore) { // ksw.c:360-361
@@ -264,18 +307,27 @@ __global__ __launch_bounds__(64, B <= 40 ? 3 : 2) void sw_lane_kernel(const uint
 	}
 }
 
-int launch_sw_lane(bmh_ctx *ctx, int b, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks, int64_t n,
+int launch_sw_lane(bmh_ctx *ctx, int b, bool corr, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks, int64_t n,
                    bmh_sw_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, uint16_t *d_rm, int rows_cap,
-                   int grid, int pass2)
+                   int grid, int pass2, uint32_t *d_next)
 {
 	if (n <= 0) return BMH_OK;
 	const long long blocks = std::min<long long>((n + 63) / 64, grid);
-#define BMH_LAUNCH_SW(BB)                                                                                               \
-	hipLaunchKernelGGL((sw_lane_kernel<BB>), dim3((unsigned)blocks), dim3(64), 0, ctx->stream, d_pool, d_tasks, d_order, \
-	                   d_count, (long long)n, d_res, ctx->dev, d_rm, rows_cap, pass2, ctx->d_err)
-	if (b == 40) BMH_LAUNCH_SW(40);
-	else if (b == 80) BMH_LAUNCH_SW(80);
+	const bool sym = ctx->dev.o_del == ctx->dev.o_ins;
+#define BMH_LAUNCH_SW(BB, SS, CC)                                                                                        \
+	hipLaunchKernelGGL((sw_lane_kernel<BB, SS, CC>), dim3((unsigned)blocks), dim3(64), 0, ctx->stream, d_pool, d_tasks,  \
+	                   d_order, d_count, (long long)n, d_res, ctx->dev, d_rm, rows_cap, pass2, ctx->d_err, d_next)
+#define BMH_LAUNCH_SW2(BB, CC)                                                                                           \
+	do {                                                                                                                 \
+		if (sym) BMH_LAUNCH_SW(BB, true, CC);                                                                            \
+		else BMH_LAUNCH_SW(BB, false, CC);                                                                               \
+	} while (0)
+	if (b == 40 && !corr) BMH_LAUNCH_SW2(40, false);
+	else if (b == 40) BMH_LAUNCH_SW2(40, true);
+	else if (b == 80 && !corr) BMH_LAUNCH_SW2(80, false);
+	else if (b == 80) BMH_LAUNCH_SW2(80, true);
 	else return BMH_E_ARG;
+#undef BMH_LAUNCH_SW2
 #undef BMH_LAUNCH_SW
 	BMH_HIP(ctx, hipGetLastError());
 	return BMH_OK;

@@ -200,3 +200,50 @@ int64_t bmh_taskgen_glb(const bmh_taskgen_cfg_t *cfg, int64_t n_reads, int wspre
 	if (cigar_words) *cigar_words = cw;
 	return nt;
 }
+
+/* Mate-rescue tasks as mem_matesw hands them to ksw_align2 (reference bwamem_pair.c:109-175): the mate (read length
+ * from cfg) against the insert-size window [low,high] + l_ms of the reference; with probability p_hit the window holds
+ * the mate's true locus (error model of cfg), otherwise it is unrelated sequence (the rescue fails, score < minsc).
+ * xtra = KSW_XSUBO | KSW_XSTART | (l_ms*a < 250 ? KSW_XBYTE : 0) | min_seed_len*a  (bwamem_pair.c:147).
+ * Returns the number of tasks (one per mate) or -1 if a capacity is too small. */
+int64_t bmh_taskgen_sw(const bmh_taskgen_cfg_t *cfg, const bmh_params_t *p, int64_t n, int win_min, int win_max,
+                       double p_hit, uint8_t *pool, size_t pool_cap, size_t *pool_used, bmh_sw_task_t *tasks,
+                       int64_t task_cap)
+{
+	const int Lmax = cfg->len_max;
+	uint8_t *ref = (uint8_t *)malloc((size_t)win_max + 2 * (size_t)Lmax + 64), *rd = (uint8_t *)malloc((size_t)Lmax + 64);
+	int64_t nt = 0, r;
+	size_t used = 0;
+	uint64_t s = cfg->seed;
+	for (r = 0; r < n; ++r) {
+		const int L = irand(&s, cfg->len_min, cfg->len_max);
+		const int W = irand(&s, win_min, win_max) + L;
+		int i, x, k = 0;
+		for (i = 0; i < W; ++i) ref[i] = (uint8_t)(splitmix(&s) & 3);
+		if (urand(&s) < p_hit) {
+			for (x = irand(&s, 0, W - L > 0 ? W - L : 0); k < L && x < W;) {
+				const double u = urand(&s);
+				if (u < cfg->p_sub) rd[k++] = (uint8_t)((ref[x++] + 1 + splitmix(&s) % 3) & 3);
+				else if (u < cfg->p_sub + cfg->p_ins) {
+					int g = irand(&s, 1, cfg->max_indel);
+					for (; g > 0 && k < L; --g) rd[k++] = (uint8_t)(splitmix(&s) & 3);
+				} else if (u < cfg->p_sub + cfg->p_ins + cfg->p_del) x += irand(&s, 1, cfg->max_indel);
+				else rd[k++] = ref[x++];
+			}
+		}
+		for (; k < L; ++k) rd[k] = (uint8_t)(splitmix(&s) & 3);
+		if (used + (size_t)L + (size_t)W + 16 > pool_cap || nt + 1 > task_cap) { nt = -1; break; }
+		{
+			bmh_sw_task_t *t = &tasks[nt++];
+			memset(t, 0, sizeof(*t));
+			memcpy(pool + used, rd, (size_t)L);
+			memcpy(pool + used + L, ref, (size_t)W);
+			t->q_off = used, t->t_off = used + (uint64_t)L, t->qlen = (uint16_t)L, t->tlen = (uint32_t)W;
+			t->xtra = BMH_SW_XSUBO | BMH_SW_XSTART | (L * p->a < 250 ? BMH_SW_XBYTE : 0) | (uint32_t)(cfg->min_seed_len * p->a);
+			used += (size_t)L + (size_t)W;
+		}
+	}
+	free(ref), free(rd);
+	if (pool_used) *pool_used = used;
+	return nt;
+}

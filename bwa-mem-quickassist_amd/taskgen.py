@@ -76,3 +76,24 @@ def generate_global(n_reads, workload="150bp", seed=11, wspread=32):
     pool = pool[: used.value + 16]
     pool[used.value:] = 0
     return pool, tasks[:nt].copy(), int(cw.value)
+
+
+def generate_sw(params, n_mates, workload="150bp", seed=13, window=(300, 700), p_hit=0.7):
+    """Returns (pool, tasks SW_TASK[]) -- one mate-rescue Smith-Waterman per simulated mate (mem_matesw's call of
+    ksw_align2, reference bwamem_pair.c:147-148): the mate against an insert-size window of the reference."""
+    from . import SW_TASK, PARAMS
+    L = _load()
+    L.bmh_taskgen_sw.restype = C.c_int64
+    cfg = Cfg(seed=seed, **WORKLOADS[workload])
+    p = np.ascontiguousarray(params, dtype=PARAMS)
+    pool = np.empty(int(n_mates) * (cfg.len_max * 2 + window[1] + 64) + 64, dtype=np.uint8)
+    tasks = np.zeros(int(n_mates) + 1, dtype=SW_TASK)
+    used = C.c_size_t(0)
+    nt = L.bmh_taskgen_sw(C.byref(cfg), p.ctypes.data_as(C.c_void_p), C.c_int64(n_mates), C.c_int(window[0]),
+                          C.c_int(window[1]), C.c_double(p_hit), pool.ctypes.data_as(C.c_void_p),
+                          C.c_size_t(pool.nbytes), C.byref(used), tasks.ctypes.data_as(C.c_void_p), C.c_int64(len(tasks)))
+    if nt < 0:
+        raise RuntimeError("taskgen capacity too small")
+    pool = pool[: used.value + 16]
+    pool[used.value:] = 0
+    return pool, tasks[:nt].copy()

@@ -219,6 +219,18 @@ def ref_sw_batch(p, pool, tasks, pac=None, l_pac=0):
     return out
 
 
+def ref_sw_batch_mt(p, pool, tasks, nthreads=1):
+    """The compiled REFERENCE ksw_align2 over all tasks on `nthreads` host threads (oracle/ref_batch_shim.c)."""
+    lib = load_ref_ksw()
+    tasks = np.ascontiguousarray(tasks, dtype=SW_TASK)
+    pool = np.ascontiguousarray(pool, dtype=np.uint8)
+    pp = np.ascontiguousarray(p, dtype=PARAMS)
+    out = np.zeros(len(tasks), dtype=SW_RES)
+    lib.ref_sw_batch_mt(pp.ctypes.data_as(C.c_void_p), pool.ctypes.data_as(C.c_void_p), tasks.ctypes.data_as(C.c_void_p),
+                        C.c_int(len(tasks)), out.ctypes.data_as(C.c_void_p), C.c_int(nthreads))
+    return out
+
+
 def orc_sw_batch(p, pool, tasks, nthreads=1, pac=None, l_pac=0):
     """OUR restatement of ksw_align2 on every task; returns (results, cells).  results["rsv"] = 1 marks inputs for
     which the reference's behaviour is undefined (byte overflow + KSW_XSTART)."""
