@@ -59,7 +59,7 @@ int ksw_extend2(int qlen, const uint8_t *query, int tlen, const uint8_t *target,
 	p.o_del = o_del, p.e_del = e_del, p.o_ins = o_ins, p.e_ins = e_ins, p.zdrop = zdrop;
 	p.a = 1, p.w = w, p.pen_clip5 = p.pen_clip3 = end_bonus;
 	memcpy(p.mat, mat, 25);
-	ctx = bmh_tls_ctx(&p);
+	ctx = bmh_tls_ctx_slot(&p, 1);
 	pool = (uint8_t *)malloc((size_t)qlen + (size_t)tlen + 16);
 	memcpy(pool, query, (size_t)qlen);
 	memcpy(pool + qlen, target, (size_t)tlen);
@@ -98,7 +98,7 @@ int ksw_global2(int qlen, const uint8_t *query, int tlen, const uint8_t *target,
 	memset(&p, 0, sizeof(p));
 	p.o_del = o_del, p.e_del = e_del, p.o_ins = o_ins, p.e_ins = e_ins, p.zdrop = 0, p.a = 1, p.w = 100;
 	memcpy(p.mat, mat, 25);
-	ctx = bmh_tls_ctx(&p);
+	ctx = bmh_tls_ctx_slot(&p, 1);
 	if (qlen > 65535 || tlen > 65535) bmh_tls_die("ksw_global2 drop-in: lengths out of range", BMH_E_RANGE);
 	pool = (uint8_t *)malloc((size_t)qlen + (size_t)tlen + 16);
 	memcpy(pool, query, (size_t)qlen);
@@ -117,4 +117,56 @@ int ksw_global2(int qlen, const uint8_t *query, int tlen, const uint8_t *target,
 		*n_cigar_ = r.n_cigar, *cigar_ = cig;
 	}
 	return r.score;
+}
+
+/* ---- local Smith-Waterman, reference ksw.h:61-62 / ksw.c:341-369 (mate rescue, short chains) */
+typedef struct { /* kswr_t, ksw.h:14-19 -- returned by value, exactly as the reference does */
+	int score;
+	int te, qe;
+	int score2, te2;
+	int tb, qb;
+} bmh_kswr_t;
+struct _kswq_t;
+typedef bmh_kswr_t (*aln2_fn)(int, uint8_t *, int, uint8_t *, int, const int8_t *, int, int, int, int, int, struct _kswq_t **);
+
+bmh_kswr_t ksw_align2(int qlen, uint8_t *query, int tlen, uint8_t *target, int m, const int8_t *mat, int o_del, int e_del,
+                      int o_ins, int e_ins, int xtra, struct _kswq_t **qry)
+{
+	bmh_params_t p;
+	bmh_sw_task_t t;
+	bmh_sw_result_t r;
+	bmh_kswr_t out;
+	uint8_t *pool;
+	bmh_ctx_t *ctx;
+	int rc;
+	if (!ksw_dropin_enabled()) {
+		static aln2_fn next;
+		if (!next) next = (aln2_fn)dlsym(RTLD_NEXT, "ksw_align2");
+		if (!next) bmh_tls_die("BMH_KSW_DROPIN=0 but no other ksw_align2 is loaded", BMH_E_ARG);
+		return next(qlen, query, tlen, target, m, mat, o_del, e_del, o_ins, e_ins, xtra, qry);
+	}
+	if (m != 5) bmh_tls_die("ksw_align2 drop-in supports m == 5 only", BMH_E_RANGE);
+	if (qlen > 65535 || qlen < 1 || tlen < 0) bmh_tls_die("ksw_align2 drop-in: lengths out of range", BMH_E_RANGE);
+	/* the reference caches its query profile in *qry and the caller free()s it (ksw.c:348-349, ksw.h:55-58); this
+	 * implementation has no profile, so hand out a small block for that free() */
+	if (qry && *qry == 0) *qry = (struct _kswq_t *)calloc(1, 16);
+	memset(&p, 0, sizeof(p));
+	p.o_del = o_del, p.e_del = e_del, p.o_ins = o_ins, p.e_ins = e_ins, p.zdrop = 0, p.a = 1, p.w = 100;
+	memcpy(p.mat, mat, 25);
+	ctx = bmh_tls_ctx_slot(&p, 1);
+	pool = (uint8_t *)malloc((size_t)qlen + (size_t)tlen + 16);
+	memcpy(pool, query, (size_t)qlen);
+	memcpy(pool + qlen, target, (size_t)tlen);
+	memset(&t, 0, sizeof(t));
+	t.q_off = 0, t.t_off = (uint64_t)qlen, t.qlen = (uint16_t)qlen, t.tlen = (uint32_t)tlen, t.xtra = (uint32_t)xtra;
+	if ((rc = bmh_sw_batch(ctx, pool, (size_t)qlen + (size_t)tlen + 16, &t, 1, &r))) bmh_tls_die(bmh_last_error(ctx), rc);
+	free(pool);
+	out.score = r.score, out.te = r.te, out.qe = r.qe, out.score2 = r.score2, out.te2 = r.te2, out.tb = r.tb, out.qb = r.qb;
+	return out;
+}
+
+bmh_kswr_t ksw_align(int qlen, uint8_t *query, int tlen, uint8_t *target, int m, const int8_t *mat, int gapo, int gape, int xtra,
+                     struct _kswq_t **qry) /* ksw.c:366-369 */
+{
+	return ksw_align2(qlen, query, tlen, target, m, mat, gapo, gape, gapo, gape, xtra, qry);
 }

@@ -5,9 +5,9 @@
 
 #include "tls_ctx.h"
 
-static __thread bmh_ctx_t *tls_ctx;
-static __thread bmh_params_t tls_params;
-static __thread int tls_have;
+static __thread bmh_ctx_t *tls_ctx_[2];
+static __thread bmh_params_t tls_params_[2];
+static __thread int tls_have_[2];
 
 void bmh_tls_die(const char *msg, int code)
 {
@@ -15,16 +15,18 @@ void bmh_tls_die(const char *msg, int code)
 	abort();
 }
 
-bmh_ctx_t *bmh_tls_ctx(const bmh_params_t *p)
+bmh_ctx_t *bmh_tls_ctx_slot(const bmh_params_t *p, int slot)
 {
 	int rc;
-	if (!tls_ctx) {
+	if (!tls_ctx_[slot]) {
 		const char *dev = getenv("BMH_DEVICE");
-		if ((rc = bmh_ctx_create(&tls_ctx, dev ? atoi(dev) : 0))) bmh_tls_die("cannot create a GPU context", rc);
+		if ((rc = bmh_ctx_create(&tls_ctx_[slot], dev ? atoi(dev) : 0))) bmh_tls_die("cannot create a GPU context", rc);
 	}
-	if (!tls_have || memcmp(&tls_params, p, sizeof(*p)) != 0) {
-		if ((rc = bmh_ctx_set_params(tls_ctx, p))) bmh_tls_die(bmh_last_error(tls_ctx), rc);
-		tls_params = *p, tls_have = 1;
+	if (!tls_have_[slot] || memcmp(&tls_params_[slot], p, sizeof(*p)) != 0) {
+		if ((rc = bmh_ctx_set_params(tls_ctx_[slot], p))) bmh_tls_die(bmh_last_error(tls_ctx_[slot]), rc);
+		tls_params_[slot] = *p, tls_have_[slot] = 1;
 	}
-	return tls_ctx;
+	return tls_ctx_[slot];
 }
+
+bmh_ctx_t *bmh_tls_ctx(const bmh_params_t *p) { return bmh_tls_ctx_slot(p, 0); }

@@ -4,7 +4,8 @@ pipeline_ref.sh: SAM of the fork == SAM of stock).
 REF = the reference compiled by oracle/Makefile (oracle/_ref/bwa), untouched.
 DUT = the same binary with libbwamem_hip_dropin.so LD_PRELOADed: phase 1 goes through the fork's
       batching seam mem_align1_core_batched -> bmh_chain2aln_batch (GPU extension kernels, one
-      context per host thread), and every ksw_global2 of phase 2 is a per-call GPU drop-in.
+      context per host thread), and every ksw_global2 of phase 2 and every ksw_align2 (short chains in
+      phase 1, mate rescue in phase 2) is a per-call GPU drop-in.
 SAM must be byte-identical except the @PG header line.  Runs first in the session (file name) so
 the parent process is GPU-clean when it starts the child processes."""
 import os
@@ -22,7 +23,7 @@ from __graft_entry__ import load_package
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not reflib.have_ref_bwa(), reason="oracle/_ref not built")]
 
 
-def _sim_reads(rng, ref, n, L, hard, pair=False):
+def _sim_reads(rng, ref, n, L, hard, pair=False, rescue=0.0):
     r1, r2 = [], []
     for _ in range(n):
         ins = int(rng.integers(250, 450)) if pair else L
@@ -38,7 +39,10 @@ def _sim_reads(rng, ref, n, L, hard, pair=False):
         if hard:
             a[rng.random(len(a)) < 0.01] = 4
         if pair:
-            b = kswgen.mutate(rng, frag[ins - L:ins + 30], sub, ind, ind, mx)[:L]
+            if rng.random() < rescue:  # too many errors for a 19-mer seed: only mate rescue (ksw_align2) can place it
+                b = kswgen.mutate(rng, frag[ins - L:ins + 30], 0.10, 0.004, 0.004, 2)[:L]
+            else:
+                b = kswgen.mutate(rng, frag[ins - L:ins + 30], sub, ind, ind, mx)[:L]
             b = (3 - b[::-1]).astype(np.uint8)
             r1.append(a), r2.append(b)
         else:
@@ -67,8 +71,9 @@ def _run(fa, fqs, out, extra, preload):
     if preload:
         env["LD_PRELOAD"] = load_package().DROPIN_PATH
     with open(out, "w") as f:
-        subprocess.run([reflib.REF_BWA, "mem", "-v", "1"] + extra + [fa] + fqs, check=True, stdout=f,
-                       stderr=subprocess.DEVNULL, env=env, timeout=600)
+        r = subprocess.run([reflib.REF_BWA, "mem", "-v", "1"] + extra + [fa] + fqs, stdout=f, stderr=subprocess.PIPE,
+                           env=env, timeout=600)
+    assert r.returncode == 0, f"bwa mem {extra} (preload={preload}) failed with {r.returncode}: {r.stderr.decode()[-2000:]}"
     return [l for l in open(out) if not l.startswith("@PG")]
 
 
@@ -96,4 +101,23 @@ def test_pe_sam_identical(genome):
     ref_sam = _run(fa, [f1, f2], os.path.join(tmp, "ref_pe.sam"), extra, False)
     dut_sam = _run(fa, [f1, f2], os.path.join(tmp, "dut_pe.sam"), extra, True)
     assert len(ref_sam) >= 2400
+    assert ref_sam == dut_sam
+
+
+def test_pe_mate_rescue_sam_identical(genome):
+    """Pairs whose second mate cannot be seeded: mem_matesw (reference bwamem_pair.c:109-175) places it with
+    ksw_align2, which the preload routes to the GPU Smith-Waterman kernels."""
+    rng, tmp, fa, ref = genome
+    r1, r2 = _sim_reads(rng, ref, 900, 150, False, pair=True, rescue=0.5)
+    h1, h2 = _sim_reads(rng, ref, 300, 125, True, pair=True, rescue=0.5)
+    f1, f2 = os.path.join(tmp, "mr_1.fq"), os.path.join(tmp, "mr_2.fq")
+    reflib.write_fastq(f1, r1 + h1, "m")
+    reflib.write_fastq(f2, r2 + h2, "m")
+    extra = ["-t", "4", "-b", "300"]
+    ref_sam = _run(fa, [f1, f2], os.path.join(tmp, "ref_mr.sam"), extra, False)
+    dut_sam = _run(fa, [f1, f2], os.path.join(tmp, "dut_mr.sam"), extra, True)
+    assert len(ref_sam) >= 2400
+    # the scenario really exercises rescue: a good share of second mates is placed although it had no seed hit
+    placed = sum(1 for l in ref_sam if not l.startswith("@") and int(l.split("\t")[1]) & 0x80 and not int(l.split("\t")[1]) & 0x4)
+    assert placed > 900
     assert ref_sam == dut_sam
