@@ -12,7 +12,7 @@
 	X(pk_mul_lo_u16, "v_pk_mul_lo_u16 %0, %0, %1") X(add3_u32, "v_add3_u32 %0, %0, %1, %1") X(pk_max_i16, "v_pk_max_i16 %0, %0, %1") \
 	X(pk_add_u16_dep, "v_pk_add_u16 %0, %0, %1")
 
-constexpr int ITERS = 500;
+constexpr int ITERS = 2000;
 
 #define KERNEL(name, text)                                                                                              \
 	__global__ void k_##name(uint32_t *out, long long *cyc, int dep)                                                    \
@@ -48,12 +48,12 @@ int main()
 	const int cus = prop.multiProcessorCount;
 	const double ghz = prop.clockRate * 1e-6;
 	printf("%d CUs, %.2f GHz; cycles per wave-instruction per SIMD (all SIMDs busy)\n", cus, ghz);
-	printf("%-20s %14s %14s %14s %14s\n", "instruction", "1w/SIMD indep", "1w/SIMD dep", "2w/SIMD indep", "2w/SIMD dep");
+	printf("%-20s %10s %10s %10s %10s %10s %10s\n", "instruction", "1w indep", "1w dep", "2w indep", "2w dep", "3w indep", "4w indep");
 #define RUN(name, text)                                                                                                 \
 	{                                                                                                                   \
-		double r[4];                                                                                                    \
-		for (int m = 0; m < 4; ++m) {                                                                                   \
-			const int wps = m < 2 ? 1 : 2, dep = m & 1;                                                                 \
+		double r[6];                                                                                                    \
+		for (int m = 0; m < 6; ++m) {                                                                                   \
+			const int wps = m < 2 ? 1 : m < 4 ? 2 : m - 1, dep = m < 4 ? (m & 1) : 0;                                                                 \
 			const int blocks = cus * 4, threads = 256 * wps; /* 4 blocks/CU x (4 or 8) waves... one block per CU below */ \
 			(void)blocks;                                                                                               \
 			hipLaunchKernelGGL(k_##name, dim3(cus), dim3(threads), 0, 0, out, cyc, dep);                                \
@@ -66,7 +66,7 @@ int main()
 			/* each SIMD ran wps waves x ITERS x 64 instructions */                                                     \
 			r[m] = ms * 1e-3 * ghz * 1e9 / ((double)wps * ITERS * 64.0);                                                \
 		}                                                                                                               \
-		printf("%-20s %14.2f %14.2f %14.2f %14.2f\n", #name, r[0], r[1], r[2], r[3]);                                   \
+		printf("%-20s %10.2f %10.2f %10.2f %10.2f %10.2f %10.2f\n", #name, r[0], r[1], r[2], r[3], r[4], r[5]);                                   \
 	}
 	OPS(RUN)
 	return 0;
