@@ -32,7 +32,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--reads", type=int, default=1_000_000, help="simulated reads per GPU per step")
     ap.add_argument("--workload", default="150bp", choices=["150bp", "mixed100-300"])
-    ap.add_argument("--sw-tasks", type=int, default=100_000,
+    ap.add_argument("--sw-tasks", type=int, default=400_000,
                     help="mate-rescue Smith-Waterman tasks for the secondary measurement (0 = skip)")
     ap.add_argument("--target-source", default="pool", choices=["pool", "pac"],
                     help="pac: targets decoded on the fly from a 2-bit reference resident in HBM (BMH_F_TPAC)")

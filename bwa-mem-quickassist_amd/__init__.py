@@ -37,6 +37,8 @@ SW_TASK = np.dtype([("q_off", "<u8"), ("t_off", "<u8"), ("tlen", "<u4"), ("qlen"
 SW_RES = np.dtype([("score", "<i4"), ("te", "<i4"), ("qe", "<i4"), ("score2", "<i4"), ("te2", "<i4"),
                    ("tb", "<i4"), ("qb", "<i4"), ("rsv", "<i4")])
 KSW_XBYTE, KSW_XSTOP, KSW_XSUBO, KSW_XSTART = 0x10000, 0x20000, 0x40000, 0x80000  # reference ksw.h:6-9
+PESTAT = np.dtype([("low", "<i4"), ("high", "<i4"), ("failed", "<i4"), ("pad", "<i4"), ("avg", "<f8"), ("std", "<f8")])
+MATESW_OPT = np.dtype([("pen_unpaired", "<i4"), ("max_matesw", "<i4"), ("min_seed_len", "<i4"), ("rsv", "<i4")])
 PARAMS = np.dtype([("o_del", "<i4"), ("e_del", "<i4"), ("o_ins", "<i4"), ("e_ins", "<i4"),
                    ("zdrop", "<i4"), ("a", "<i4"), ("w", "<i4"), ("pen_clip5", "<i4"),
                    ("pen_clip3", "<i4"), ("mat", "i1", (25,)), ("pad", "i1", (3,))])
@@ -102,6 +104,8 @@ def lib():
         L.bmh_upload_pool.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.bmh_extend_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int64, C.c_void_p]
         L.bmh_extend_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.bmh_matesw_batch.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.bmh_sw_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int64, C.c_void_p]
         L.bmh_sw_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.bmh_extend_batch_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_size_t, C.c_void_p,
@@ -121,6 +125,8 @@ def lib():
 
 _libc = C.CDLL(None)
 _libc.free.argtypes = [C.c_void_p]
+_libc.malloc.restype = C.c_void_p
+_libc.malloc.argtypes = [C.c_size_t]
 
 
 def _ptr(a):
@@ -217,6 +223,42 @@ class Context:
 
     def sw_batch_device(self, d_pool, d_tasks, n, d_res):
         self._check(lib().bmh_sw_batch_device(self._h, C.c_void_p(d_pool), C.c_void_p(d_tasks), int(n), C.c_void_p(d_res)))
+
+    def matesw_batch(self, l_pac, pac, reads, regs, pes, opt, dedup):
+        """Batched mate rescue (reference bwamem_pair.c:251-263 over mem_matesw :109-175) for len(reads)//2 pairs.
+        reads: flat list of uint8 code arrays (2 per pair); regs: flat list of ALNREG arrays; pes: PESTAT[4];
+        opt: MATESW_OPT record; dedup: C function pointer with the bmh_dedup_fn shape.
+        Returns (regs after rescue, n per pair)."""
+        n_pairs = len(reads) // 2
+        pac = np.ascontiguousarray(pac, dtype=np.uint8)
+        pes = np.ascontiguousarray(pes, dtype=PESTAT)
+        opt = np.ascontiguousarray(opt, dtype=MATESW_OPT)
+        keep = []
+        c_reads = (_Read * len(reads))()
+        for k, r in enumerate(reads):
+            r = np.ascontiguousarray(r, dtype=np.uint8)
+            keep.append(r)
+            c_reads[k].l_seq, c_reads[k].seq = len(r), r.ctypes.data
+        c_regs = (_AlnregV * len(regs))()
+        for k, r in enumerate(regs):
+            r = np.ascontiguousarray(r, dtype=ALNREG)
+            c_regs[k].n = c_regs[k].m = len(r)
+            if len(r):
+                c_regs[k].a = _libc.malloc(len(r) * ALNREG.itemsize)
+                C.memmove(c_regs[k].a, r.ctypes.data, len(r) * ALNREG.itemsize)
+        n_sw = np.zeros(max(n_pairs, 1), dtype=np.int32)
+        rc = lib().bmh_matesw_batch(self._h, C.c_int64(l_pac), _ptr(pac), n_pairs, C.cast(c_reads, C.c_void_p),
+                                    C.cast(c_regs, C.c_void_p), _ptr(pes), _ptr(opt), dedup, None, _ptr(n_sw))
+        out = []
+        for k in range(len(regs)):
+            a = np.zeros(c_regs[k].n, dtype=ALNREG)
+            if c_regs[k].n:
+                C.memmove(a.ctypes.data, c_regs[k].a, c_regs[k].n * ALNREG.itemsize)
+            if c_regs[k].a:
+                _libc.free(c_regs[k].a)
+            out.append(a)
+        self._check(rc)
+        return out, n_sw[:n_pairs].tolist()
 
     def extend_batch_device(self, d_pool, d_tasks, n, d_res, d_order=0):
         self._check(lib().bmh_extend_batch_device(self._h, C.c_void_p(d_pool), C.c_void_p(d_tasks), int(n),

@@ -1,0 +1,248 @@
+/*
+ * matesw_batch.c -- batched mate rescue: the loop of mem_sam_pe (reference bwa-0.7.8/bwamem_pair.c:251-263) over
+ * mem_matesw (bwamem_pair.c:109-175) for a whole chunk of read pairs, its ksw_align2 calls run as GPU batches.
+ *
+ * What is sequential in the reference stays sequential here: every mem_matesw invocation first tests the four
+ * orientations against the CURRENT content of the mate's region vector (:112-121), which earlier invocations of the
+ * same pair may have changed.  So each pair is a small resumable machine {end i, hit j}; a ROUND advances every
+ * unfinished pair to its next invocation that really needs Smith-Waterman, collects the up to four ksw_align2 calls of
+ * that invocation (they are independent: skip[] is fixed at :112-121), runs all of them in one bmh_sw_batch, and folds
+ * the results in the reference's order (:150-166 insert, :168 mem_sort_and_dedup after every orientation).
+ * No speculation: exactly the calls the reference makes are made.
+ *
+ * Sequences: the pool holds every read once.  A reverse-complemented mate (:130-133) is BMH_F_QREV|BMH_F_QCOMP; with
+ * the reference resident on the device the window bns_get_seq would return (:143) is a BMH_F_TPAC task, otherwise it
+ * is decoded on the host into the round's pool.
+ */
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/bwamem_hip.h"
+
+const bmh_params_t *bmh_ctx_params_(const bmh_ctx_t *ctx);
+int bmh_ctx_has_pac_(const bmh_ctx_t *ctx, const uint8_t *pac, int64_t l_pac);
+
+typedef struct {
+	bmh_alnreg_v b[2];  /* hits of each end within pen_unpaired of its best, copied up front (bwamem_pair.c:252-257) */
+	int i, j;           /* next invocation: hit j of end i rescues the mate !i */
+	int n;              /* sum of mem_matesw's return values */
+	int done;
+	/* the invocation in flight */
+	int skip[4], task[4];
+	int64_t rb[4], re[4];
+} pair_t;
+
+/* mem_infer_dir, bwamem_pair.c:23-30 */
+static int infer_dir(int64_t l_pac, int64_t b1, int64_t b2, int64_t *dist)
+{
+	const int r1 = b1 >= l_pac, r2 = b2 >= l_pac;
+	const int64_t p2 = r1 == r2 ? b2 : (l_pac << 1) - 1 - b2;
+	*dist = p2 > b1 ? p2 - b1 : b1 - p2;
+	return (r1 == r2 ? 0 : 1) ^ (p2 > b1 ? 0 : 3);
+}
+
+static void push_reg(bmh_alnreg_v *v, const bmh_alnreg_t *x) /* kv_push, kvec.h:68-74 */
+{
+	if (v->n == v->m) {
+		v->m = v->m ? v->m << 1 : 2;
+		v->a = (bmh_alnreg_t *)realloc(v->a, sizeof(bmh_alnreg_t) * v->m);
+	}
+	v->a[v->n++] = *x;
+}
+
+static void fetch_window(int64_t l_pac, const uint8_t *pac, int64_t beg, int64_t end, uint8_t *dst) /* bntseq.c:355-376 */
+{
+	int64_t k, l = 0;
+	if (beg >= l_pac) {
+		const int64_t lo = (l_pac << 1) - 1 - end, hi = (l_pac << 1) - 1 - beg;
+		for (k = hi; k > lo; --k) dst[l++] = (uint8_t)(3 - (pac[k >> 2] >> ((~k & 3) << 1) & 3));
+	} else
+		for (k = beg; k < end; ++k) dst[l++] = (uint8_t)(pac[k >> 2] >> ((~k & 3) << 1) & 3);
+}
+
+int bmh_matesw_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n_pairs, const bmh_read_t *reads,
+                     bmh_alnreg_v *regs, const bmh_pestat_t pes[4], const bmh_matesw_opt_t *o, bmh_dedup_fn dedup,
+                     void *dedup_user, int *n_sw)
+{
+	const bmh_params_t *P;
+	pair_t *ps = 0;
+	uint64_t *read_off = 0;
+	uint8_t *pool = 0;
+	bmh_sw_task_t *tasks = 0;
+	bmh_sw_result_t *res = 0;
+	size_t reads_bytes = 0, pool_cap = 0, task_cap = 0;
+	int p, r, rc = BMH_OK, tpac, first_round = 1;
+
+	if (!ctx || !pac || !reads || !regs || !pes || !o || !dedup || n_pairs < 0 || l_pac <= 0) return BMH_E_ARG;
+	if (!(P = bmh_ctx_params_(ctx))) return BMH_E_ARG;
+	if (n_pairs == 0) return BMH_OK;
+	tpac = bmh_ctx_has_pac_(ctx, pac, l_pac);
+	ps = (pair_t *)calloc((size_t)n_pairs, sizeof(pair_t));
+	read_off = (uint64_t *)malloc(sizeof(uint64_t) * 2 * (size_t)n_pairs);
+	if (!ps || !read_off) { rc = BMH_E_NOMEM; goto done; }
+	for (p = 0; p < 2 * n_pairs; ++p) {
+		if (reads[p].l_seq < 1 || reads[p].l_seq > 65535) { rc = BMH_E_RANGE; goto done; }
+		read_off[p] = reads_bytes, reads_bytes += (size_t)reads[p].l_seq;
+	}
+	for (p = 0; p < n_pairs; ++p) { /* bwamem_pair.c:252-257 */
+		int i;
+		size_t j;
+		for (i = 0; i < 2; ++i) {
+			const bmh_alnreg_v *a = &regs[2 * p + i];
+			for (j = 0; j < a->n; ++j)
+				if (a->a[j].score >= a->a[0].score - o->pen_unpaired) push_reg(&ps[p].b[i], &a->a[j]);
+		}
+	}
+
+	for (;;) {
+		size_t n_tasks = 0, win_bytes = 0, used;
+		int active = 0;
+		/* ---- advance every unfinished pair to its next invocation that needs ksw_align2 */
+		for (p = 0; p < n_pairs; ++p) {
+			pair_t *s = &ps[p];
+			while (!s->done) {
+				const bmh_alnreg_t *a;
+				const bmh_alnreg_v *ma;
+				int l_ms, need = 0;
+				size_t k;
+				while (s->i < 2 && !((size_t)s->j < s->b[s->i].n && s->j < o->max_matesw)) ++s->i, s->j = 0; /* :258-259 */
+				if (s->i == 2) { s->done = 1; break; }
+				a = &s->b[s->i].a[s->j], ma = &regs[2 * p + !s->i], l_ms = reads[2 * p + !s->i].l_seq;
+				for (r = 0; r < 4; ++r) s->skip[r] = pes[r].failed ? 1 : 0, s->task[r] = -1; /* :112-121 */
+				for (k = 0; k < ma->n; ++k) {
+					int64_t dist;
+					r = infer_dir(l_pac, a->rb, ma->a[k].rb, &dist);
+					if (dist >= pes[r].low && dist <= pes[r].high) s->skip[r] = 1;
+				}
+				if (s->skip[0] + s->skip[1] + s->skip[2] + s->skip[3] == 4) { ++s->j; continue; } /* :122, returns 0 */
+				for (r = 0; r < 4; ++r) { /* :123-142 */
+					int is_rev, is_larger;
+					int64_t rb, re;
+					if (s->skip[r]) continue;
+					is_rev = (r >> 1 != (r & 1)), is_larger = !(r >> 1);
+					if (!is_rev) {
+						rb = is_larger ? a->rb + pes[r].low : a->rb - pes[r].high;
+						re = (is_larger ? a->rb + pes[r].high : a->rb - pes[r].low) + l_ms;
+					} else {
+						rb = (is_larger ? a->rb + pes[r].low : a->rb - pes[r].high) - l_ms;
+						re = is_larger ? a->rb + pes[r].high : a->rb - pes[r].low;
+					}
+					if (rb < 0) rb = 0;
+					if (re > l_pac << 1) re = l_pac << 1;
+					s->rb[r] = rb, s->re[r] = re;
+					/* bns_get_seq hands back re-rb bases unless the interval is inverted or bridges the two strands
+					 * (bntseq.c:358-375); only then does mem_matesw call ksw_align2 (:144).  An empty window is still a call:
+					 * it scores 0, inserts nothing and counts (task -2, no GPU work) */
+					if (re == rb) s->task[r] = -2;
+					else if (re > rb && (rb >= l_pac || re <= l_pac)) s->task[r] = 1, ++need, win_bytes += (size_t)(re - rb);
+				}
+				(void)need;
+				break; /* this invocation is in flight (possibly with zero tasks: it still runs the fold below) */
+			}
+			if (!s->done) ++active;
+		}
+		if (!active) break;
+
+		/* ---- build the round's tasks (and, without a resident reference, its windows) */
+		{
+			size_t want_tasks = 0;
+			for (p = 0; p < n_pairs; ++p)
+				if (!ps[p].done)
+					for (r = 0; r < 4; ++r) want_tasks += ps[p].task[r] > 0;
+			if (want_tasks > task_cap) {
+				task_cap = want_tasks + want_tasks / 2 + 64;
+				free(tasks), free(res);
+				tasks = (bmh_sw_task_t *)malloc(sizeof(bmh_sw_task_t) * task_cap);
+				res = (bmh_sw_result_t *)malloc(sizeof(bmh_sw_result_t) * task_cap);
+				if (!tasks || !res) { rc = BMH_E_NOMEM; goto done; }
+			}
+		}
+		used = reads_bytes;
+		if (first_round || !tpac) {
+			const size_t need_bytes = reads_bytes + (tpac ? 0 : win_bytes) + 16;
+			if (need_bytes > pool_cap) {
+				pool_cap = need_bytes + need_bytes / 2;
+				free(pool);
+				if (!(pool = (uint8_t *)malloc(pool_cap))) { rc = BMH_E_NOMEM; goto done; }
+				first_round = 1;
+			}
+			if (first_round)
+				for (p = 0; p < 2 * n_pairs; ++p) memcpy(pool + read_off[p], reads[p].seq, (size_t)reads[p].l_seq);
+		}
+		for (p = 0; p < n_pairs; ++p) {
+			pair_t *s = &ps[p];
+			if (s->done) continue;
+			for (r = 0; r < 4; ++r) {
+				bmh_sw_task_t *t;
+				const int mate = 2 * p + !s->i, l_ms = reads[mate].l_seq, is_rev = (r >> 1 != (r & 1));
+				if (s->task[r] <= 0) continue;
+				t = &tasks[n_tasks];
+				memset(t, 0, sizeof(*t));
+				t->qlen = (uint16_t)l_ms, t->tlen = (uint32_t)(s->re[r] - s->rb[r]);
+				t->q_off = is_rev ? read_off[mate] + (uint64_t)l_ms - 1 : read_off[mate]; /* :130-133 without the copy */
+				t->flags = is_rev ? BMH_F_QREV | BMH_F_QCOMP : 0;
+				if (tpac) t->t_off = (uint64_t)s->rb[r], t->flags |= BMH_F_TPAC;
+				else {
+					fetch_window(l_pac, pac, s->rb[r], s->re[r], pool + used);
+					t->t_off = used, used += (size_t)(s->re[r] - s->rb[r]);
+				}
+				t->xtra = BMH_SW_XSUBO | BMH_SW_XSTART | (l_ms * P->a < 250 ? BMH_SW_XBYTE : 0) | (uint32_t)(o->min_seed_len * P->a); /* :147 */
+				s->task[r] = (int)n_tasks + 1; /* 1-based index of its result */
+				++n_tasks;
+			}
+		}
+		if (n_tasks) {
+			memset(pool + used, 0, 16);
+			if (first_round || !tpac) {
+				if ((rc = bmh_upload_pool(ctx, pool, used + 16))) goto done;
+				first_round = 0;
+			}
+			if ((rc = bmh_sw_batch(ctx, 0, 0, tasks, (int64_t)n_tasks, res))) goto done;
+		}
+
+		/* ---- fold, in the reference's order (:143-170) */
+		for (p = 0; p < n_pairs; ++p) {
+			pair_t *s = &ps[p];
+			bmh_alnreg_v *ma;
+			int n = 0, l_ms;
+			if (s->done) continue;
+			ma = &regs[2 * p + !s->i], l_ms = reads[2 * p + !s->i].l_seq;
+			for (r = 0; r < 4; ++r) {
+				if (s->skip[r]) continue;
+				if (s->task[r] > 0) {
+					const bmh_sw_result_t *aln = &res[s->task[r] - 1];
+					const int is_rev = (r >> 1 != (r & 1));
+					const int64_t rb = s->rb[r];
+					if (aln->score >= o->min_seed_len && aln->qb >= 0) { /* :150-166 */
+						bmh_alnreg_t b;
+						size_t i, tmp;
+						memset(&b, 0, sizeof(b));
+						b.qb = is_rev ? l_ms - (aln->qe + 1) : aln->qb;
+						b.qe = is_rev ? l_ms - aln->qb : aln->qe + 1;
+						b.rb = is_rev ? (l_pac << 1) - (rb + aln->te + 1) : rb + aln->tb;
+						b.re = is_rev ? (l_pac << 1) - (rb + aln->tb) : rb + aln->te + 1;
+						b.score = aln->score, b.csub = aln->score2, b.secondary = -1;
+						b.seedcov = (int32_t)((b.re - b.rb < b.qe - b.qb ? b.re - b.rb : b.qe - b.qb) >> 1);
+						push_reg(ma, &b); /* make room, then move b so that ma stays sorted by score */
+						for (i = 0; i < ma->n - 1; ++i)
+							if (ma->a[i].score < b.score) break;
+						tmp = i;
+						for (i = ma->n - 1; i > tmp; --i) ma->a[i] = ma->a[i - 1];
+						ma->a[i] = b;
+					}
+					++n;
+				} else if (s->task[r] == -2) ++n;
+				if (n) ma->n = (size_t)dedup(dedup_user, (int)ma->n, ma->a); /* :168 */
+			}
+			s->n += n;
+			++s->j;
+		}
+	}
+	if (n_sw)
+		for (p = 0; p < n_pairs; ++p) n_sw[p] = ps[p].n;
+done:
+	if (ps)
+		for (p = 0; p < n_pairs; ++p) free(ps[p].b[0].a), free(ps[p].b[1].a);
+	free(ps), free(read_off), free(pool), free(tasks), free(res);
+	return rc;
+}

@@ -292,6 +292,35 @@ int bmh_sw_batch(bmh_ctx_t *ctx, const uint8_t *pool, size_t pool_bytes, const b
 int bmh_sw_batch_device(bmh_ctx_t *ctx, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks, int64_t n,
                         bmh_sw_result_t *d_results);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Batched mate rescue: the loop mem_sam_pe runs per pair (reference bwamem_pair.c:251-263) over mem_matesw
+ * (bwamem_pair.c:109-175), for a whole chunk of pairs.
+ *   reads[2p], reads[2p+1]   the two mates of pair p (base codes), regs[2p], regs[2p+1] their region vectors as
+ *                            phase 1 left them (mem_alnreg_v, layout-compatible); rescued regions are inserted into
+ *                            the MATE's vector exactly as the reference does (kv_push growth, score-sorted insert,
+ *                            then mem_sort_and_dedup)
+ *   pes[4]                   mem_pestat_t per orientation (bwamem.h:66-70), opt fields of mem_opt_t in `o`
+ *   dedup                    the caller's mem_sort_and_dedup(n, a, opt->mask_level_redun) (bwamem.c:395); it is host
+ *                            post-processing outside this path, so the reference's own function is passed in
+ *   n_sw[p] (nullable)       the sum of mem_matesw's return values for pair p
+ * Each mem_matesw invocation tests its four orientations against the current state of the mate's vector, so the
+ * invocations of one pair are sequential; the driver runs them as rounds -- one invocation per unfinished pair and
+ * round, its up to four ksw_align2 calls as one GPU batch over all pairs.  Exactly the reference's calls are made.
+ * With the reference resident (bmh_ctx_set_pac, same pac pointer) the windows are BMH_F_TPAC tasks and the
+ * reverse-complemented mate is BMH_F_QREV|BMH_F_QCOMP: the pool holds every read once and nothing else. */
+typedef struct bmh_pestat { /* mem_pestat_t, bwamem.h:66-70 */
+	int32_t low, high;
+	int32_t failed;
+	double avg, std;
+} bmh_pestat_t;
+typedef struct bmh_matesw_opt { /* the mem_opt_t fields mem_sam_pe / mem_matesw read beside the scoring (bwamem.h:21-48) */
+	int32_t pen_unpaired, max_matesw, min_seed_len, rsv;
+} bmh_matesw_opt_t;
+typedef int (*bmh_dedup_fn)(void *user, int n, bmh_alnreg_t *a);
+int bmh_matesw_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n_pairs, const bmh_read_t *reads,
+                     bmh_alnreg_v *regs, const bmh_pestat_t pes[4], const bmh_matesw_opt_t *o, bmh_dedup_fn dedup,
+                     void *dedup_user, int *n_sw);
+
 #ifdef __cplusplus
 }
 #endif

@@ -40,6 +40,9 @@ SW_TASK = np.dtype([("q_off", "<u8"), ("t_off", "<u8"), ("tlen", "<u4"), ("qlen"
 SW_RES = np.dtype([("score", "<i4"), ("te", "<i4"), ("qe", "<i4"), ("score2", "<i4"), ("te2", "<i4"),
                    ("tb", "<i4"), ("qb", "<i4"), ("rsv", "<i4")])
 KSW_XBYTE, KSW_XSTOP, KSW_XSUBO, KSW_XSTART = 0x10000, 0x20000, 0x40000, 0x80000  # reference ksw.h:6-9
+PESTAT = np.dtype([("low", "<i4"), ("high", "<i4"), ("failed", "<i4"), ("pad", "<i4"), ("avg", "<f8"), ("std", "<f8")])
+MATESW_OPT = np.dtype([("pen_unpaired", "<i4"), ("max_matesw", "<i4"), ("min_seed_len", "<i4"), ("rsv", "<i4")])
+assert PESTAT.itemsize == 32
 SW_FIELDS = ("score", "te", "qe", "score2", "te2", "tb", "qb")
 assert SW_TASK.itemsize == 32 and SW_RES.itemsize == 32
 assert EXT_TASK.itemsize == 32 and EXT_RES.itemsize == 24
@@ -430,3 +433,97 @@ def orc_global_batch_mt(p, pool, tasks, cigar_words, nthreads=1):
                          C.c_int(len(tasks)), res.ctypes.data_as(C.c_void_p), cig.ctypes.data_as(C.c_void_p),
                          C.byref(cells), C.c_int(nthreads))
     return res, cig, cells.value
+
+
+# ---- mate rescue (mem_matesw loop) ------------------------------------------------------------------------------
+class CRead(C.Structure):  # bmh_read_t
+    _fields_ = [("l_seq", C.c_int32), ("seq", C.c_void_p)]
+
+
+class CAlnregV(C.Structure):  # bmh_alnreg_v == mem_alnreg_v
+    _fields_ = [("n", C.c_size_t), ("m", C.c_size_t), ("a", C.c_void_p)]
+
+
+DEDUP_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p)
+_libc = C.CDLL(None)
+_libc.malloc.restype = C.c_void_p
+_libc.malloc.argtypes = [C.c_size_t]
+_libc.free.argtypes = [C.c_void_p]
+
+
+def regs_to_c(regs_list):
+    """List of ALNREG arrays -> C array of bmh_alnreg_v whose .a are malloc()ed (the callee realloc()s them)."""
+    arr = (CAlnregV * len(regs_list))()
+    for k, r in enumerate(regs_list):
+        r = np.ascontiguousarray(r, dtype=ALNREG)
+        arr[k].n = arr[k].m = len(r)
+        if len(r):
+            arr[k].a = _libc.malloc(len(r) * ALNREG.itemsize)
+            C.memmove(arr[k].a, r.ctypes.data, len(r) * ALNREG.itemsize)
+    return arr
+
+
+def regs_from_c(arr, free=True):
+    out = []
+    for k in range(len(arr)):
+        r = np.zeros(arr[k].n, dtype=ALNREG)
+        if arr[k].n:
+            C.memmove(r.ctypes.data, arr[k].a, arr[k].n * ALNREG.itemsize)
+        if free and arr[k].a:
+            _libc.free(arr[k].a)
+        out.append(r)
+    return out
+
+
+def reads_to_c(reads, keep):
+    arr = (CRead * len(reads))()
+    for k, r in enumerate(reads):
+        r = np.ascontiguousarray(r, dtype=np.uint8)
+        keep.append(r)
+        arr[k].l_seq, arr[k].seq = len(r), r.ctypes.data
+    return arr
+
+
+def simple_dedup_fn():
+    """orc_simple_dedup as a C function pointer (shared by DUT and oracle where the reference is absent)."""
+    return C.cast(load_oracle().orc_simple_dedup, C.c_void_p)
+
+
+def orc_matesw_pairs(p, o, l_pac, pac, pes, reads, regs, dedup):
+    """OUR sequential restatement of the mate-rescue block of mem_sam_pe over every pair.
+    reads/regs: flat lists, 2 per pair.  Returns (regs after rescue, n per pair)."""
+    lib = load_oracle()
+    lib.orc_matesw_pair.restype = C.c_int
+    pp = np.ascontiguousarray(p, dtype=PARAMS)
+    oo = np.ascontiguousarray(o, dtype=MATESW_OPT)
+    pes = np.ascontiguousarray(pes, dtype=PESTAT)
+    pac = np.ascontiguousarray(pac, dtype=np.uint8)
+    keep = []
+    c_reads = reads_to_c(reads, keep)
+    c_regs = regs_to_c(regs)
+    ns = []
+    for k in range(len(reads) // 2):
+        ns.append(lib.orc_matesw_pair(pp.ctypes.data_as(C.c_void_p), oo.ctypes.data_as(C.c_void_p), C.c_int64(l_pac),
+                                      pac.ctypes.data_as(C.c_void_p), pes.ctypes.data_as(C.c_void_p),
+                                      C.byref(c_reads, 2 * k * C.sizeof(CRead)), C.byref(c_regs, 2 * k * C.sizeof(CAlnregV)),
+                                      dedup, None))
+    return regs_from_c(c_regs), ns
+
+
+def golden_matesw_groups():
+    """Yields (params, opt, pes, l_pac, pac, reads, regs, expect_regs, n_sw) per group of matesw_golden.npz."""
+    g = load_golden("matesw_golden.npz")
+    l_pac, pac = int(g["l_pac"]), g["pac"]
+
+    def split(flat, counts):
+        out, o = [], 0
+        for c in counts:
+            out.append(flat[o:o + c].copy())
+            o += c
+        return out
+    for key in g["groups"]:
+        key = str(key)
+        reads = split(g[key + "reads"], g[key + "read_len"])
+        regs = split(g[key + "regs"], g[key + "regs_n"])
+        exp = split(g[key + "exp"], g[key + "exp_n"])
+        yield g[key + "params"], g[key + "opt"], g[key + "pes"], l_pac, pac, reads, regs, exp, g[key + "n_sw"].tolist()

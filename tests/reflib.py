@@ -166,3 +166,73 @@ def ref_reg2aln(idx, opt, read, reg):
     if a.cigar:
         _libc.free(C.cast(a.cigar, C.c_void_p))
     return out
+
+
+# ---- paired-end pieces: phase 1 per read, insert-size statistics, the reference's own mate rescue -------------------
+def ref_align_reads(idx, opt, reads):
+    """mem_align1_core (reference bwamem.c:1122) per read -> list of ALNREG arrays."""
+    L = lib()
+    L.mem_align1_core.restype = AlnregV
+    L.mem_align1_core.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    out = []
+    for r in reads:
+        seq = np.ascontiguousarray(r, dtype=np.uint8).copy()  # mutated to codes in place (already codes here)
+        v = L.mem_align1_core(opt, idx.contents.bwt, idx.contents.bns, idx.contents.pac, len(seq), seq.ctypes.data_as(C.c_void_p))
+        a = np.zeros(v.n, dtype=kswlib.ALNREG)
+        if v.n:
+            C.memmove(a.ctypes.data, v.a, v.n * kswlib.ALNREG.itemsize)
+        if v.a:
+            _libc.free(v.a)
+        out.append(a)
+    return out
+
+
+def ref_pestat(idx, opt, regs):
+    """mem_pestat (reference bwamem_pair.c:46-107) over all pairs -> PESTAT[4]."""
+    L = lib()
+    l_pac = idx.contents.bns.contents.l_pac
+    c_regs = kswlib.regs_to_c(regs)
+    pes = np.zeros(4, dtype=kswlib.PESTAT)
+    L.mem_pestat.restype = None
+    L.mem_pestat(opt, C.c_int64(l_pac), C.c_int(len(regs)), c_regs, pes.ctypes.data_as(C.c_void_p))
+    kswlib.regs_from_c(c_regs)
+    return pes
+
+
+def ref_dedup_fn(opt):
+    """The reference's mem_sort_and_dedup(n, a, opt->mask_level_redun) (bwamem.c:395) behind the bmh_dedup_fn shape."""
+    L = lib()
+    L.mem_sort_and_dedup.restype = C.c_int
+    L.mem_sort_and_dedup.argtypes = [C.c_int, C.c_void_p, C.c_float]
+    lvl = float(opt.contents.mask_level_redun)
+    return kswlib.DEDUP_FN(lambda user, n, a: L.mem_sort_and_dedup(n, a, lvl))
+
+
+def ref_matesw_pairs(idx, opt, pes, reads, regs):
+    """The mate-rescue block of mem_sam_pe (reference bwamem_pair.c:251-263), driven from here with the reference's
+    OWN mem_matesw.  Returns (regs after rescue, n per pair)."""
+    L = lib()
+    l_pac = idx.contents.bns.contents.l_pac
+    L.mem_matesw.restype = C.c_int
+    L.mem_matesw.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    pes = np.ascontiguousarray(pes, dtype=kswlib.PESTAT)
+    c_regs = kswlib.regs_to_c(regs)
+    ns = []
+    o = opt.contents
+    for k in range(len(reads) // 2):
+        a = [np.zeros(0, kswlib.ALNREG), np.zeros(0, kswlib.ALNREG)]
+        for i in range(2):
+            v = c_regs[2 * k + i]
+            cur = np.zeros(v.n, dtype=kswlib.ALNREG)
+            if v.n:
+                C.memmove(cur.ctypes.data, v.a, v.n * kswlib.ALNREG.itemsize)
+            a[i] = cur[cur["score"] >= cur["score"][0] - o.pen_unpaired].copy() if len(cur) else cur
+        n = 0
+        for i in range(2):
+            mate = np.ascontiguousarray(reads[2 * k + (1 - i)], dtype=np.uint8)
+            for j in range(min(len(a[i]), o.max_matesw)):
+                hit = np.ascontiguousarray(a[i][j:j + 1])
+                n += L.mem_matesw(opt, l_pac, idx.contents.pac, pes.ctypes.data_as(C.c_void_p), hit.ctypes.data_as(C.c_void_p),
+                                  len(mate), mate.ctypes.data_as(C.c_void_p), C.byref(c_regs, (2 * k + 1 - i) * C.sizeof(kswlib.CAlnregV)))
+        ns.append(n)
+    return kswlib.regs_from_c(c_regs), ns

@@ -119,3 +119,30 @@ def test_sw_refuses_what_it_cannot_do_exactly():
     with pytest.raises(pkg.BmhError):
         ctx.sw_batch(pool, t)
     ctx.close()
+
+
+def test_sw_edge_sizes():
+    """Empty targets, single-base queries, and tasks far beyond the register kernels (long queries in word mode,
+    long targets) -- the catch-all kernel must agree with the oracle there too."""
+    rng = np.random.default_rng(151)
+    p = kswlib.make_params()
+    pb = kswgen.PoolBuilder(kswlib.SW_TASK)
+    X = kswlib.KSW_XSUBO | kswlib.KSW_XSTART | 19
+    for qlen, tlen, xtra in [(1, 0, X), (1, 1, X | kswlib.KSW_XBYTE), (150, 0, X | kswlib.KSW_XBYTE), (1, 500, 0),
+                             (16, 16, X | kswlib.KSW_XBYTE), (17, 33, X), (160, 700, X | kswlib.KSW_XBYTE),
+                             (161, 700, X | kswlib.KSW_XBYTE), (249, 900, X | kswlib.KSW_XBYTE), (250, 900, X),
+                             (1200, 5000, X), (3000, 12000, kswlib.KSW_XSTART), (40, 30000, X | kswlib.KSW_XBYTE)]:
+        t = kswgen.rand_seq(rng, tlen)
+        q = kswgen.rand_seq(rng, qlen)
+        if tlen > qlen + 10:
+            st = int(rng.integers(0, tlen - qlen))
+            q = kswgen.mutate(rng, t[st:st + qlen + 8], sub=0.04, ins=0.004, dele=0.004, max_indel=4)[:qlen]
+            if len(q) < qlen:
+                q = np.concatenate([q, kswgen.rand_seq(rng, qlen - len(q))])
+        kswgen._add_sw(pb, rng, q, t, xtra)
+    pool, tasks = pb.finish()
+    want, _ = kswlib.orc_sw_batch(p, pool, tasks, nthreads=8)
+    assert (want["rsv"] == 0).all()
+    ctx = _ctx_with({})
+    _cmp(ctx.sw_batch(pool, tasks), want, tasks, "edge sizes")
+    ctx.close()
