@@ -21,6 +21,7 @@
 
 const bmh_params_t *bmh_ctx_params_(const bmh_ctx_t *ctx);
 int bmh_ctx_has_pac_(const bmh_ctx_t *ctx, const uint8_t *pac, int64_t l_pac);
+void bmh_ctx_set_driver_stats_(bmh_ctx_t *ctx, const bmh_driver_stats_t *st);
 
 typedef struct {
 	bmh_alnreg_v b[2];  /* hits of each end within pen_unpaired of its best, copied up front (bwamem_pair.c:252-257) */
@@ -72,6 +73,8 @@ int bmh_matesw_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n_pa
 	bmh_sw_result_t *res = 0;
 	size_t reads_bytes = 0, pool_cap = 0, task_cap = 0;
 	int p, r, rc = BMH_OK, tpac, first_round = 1;
+	bmh_driver_stats_t st;
+	memset(&st, 0, sizeof(st));
 
 	if (!ctx || !pac || !reads || !regs || !pes || !o || !dedup || n_pairs < 0 || l_pac <= 0) return BMH_E_ARG;
 	if (!(P = bmh_ctx_params_(ctx))) return BMH_E_ARG;
@@ -192,8 +195,10 @@ int bmh_matesw_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n_pa
 			}
 		}
 		if (n_tasks) {
+			++st.rounds, st.ext_tasks += (int64_t)n_tasks; /* here: GPU rounds and ksw_align2 calls */
 			memset(pool + used, 0, 16);
 			if (first_round || !tpac) {
+				st.pool_bytes += (int64_t)used + 16;
 				if ((rc = bmh_upload_pool(ctx, pool, used + 16))) goto done;
 				first_round = 0;
 			}
@@ -241,6 +246,7 @@ int bmh_matesw_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n_pa
 	if (n_sw)
 		for (p = 0; p < n_pairs; ++p) n_sw[p] = ps[p].n;
 done:
+	bmh_ctx_set_driver_stats_(ctx, &st);
 	if (ps)
 		for (p = 0; p < n_pairs; ++p) free(ps[p].b[0].a), free(ps[p].b[1].a);
 	free(ps), free(read_off), free(pool), free(tasks), free(res);

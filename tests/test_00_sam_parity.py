@@ -4,8 +4,9 @@ pipeline_ref.sh: SAM of the fork == SAM of stock).
 REF = the reference compiled by oracle/Makefile (oracle/_ref/bwa), untouched.
 DUT = the same binary with libbwamem_hip_dropin.so LD_PRELOADed: phase 1 goes through the fork's
       batching seam mem_align1_core_batched -> bmh_chain2aln_batch (GPU extension kernels, one
-      context per host thread), and every ksw_global2 of phase 2 and every ksw_align2 (short chains in
-      phase 1, mate rescue in phase 2) is a per-call GPU drop-in.
+      context per host thread); for pairs, mem_process_seqs itself is taken over so that the whole chunk's mate
+      rescue (mem_matesw, ksw_align2) runs as bmh_matesw_batch; every ksw_global2 of phase 2 and the ksw_align2 of
+      short chains are per-call GPU drop-ins.
 SAM must be byte-identical except the @PG header line.  Runs first in the session (file name) so
 the parent process is GPU-clean when it starts the child processes."""
 import os
@@ -70,10 +71,12 @@ def _run(fa, fqs, out, extra, preload):
     env = dict(os.environ)
     if preload:
         env["LD_PRELOAD"] = load_package().DROPIN_PATH
+        env["BMH_VERBOSE"] = "1"
     with open(out, "w") as f:
         r = subprocess.run([reflib.REF_BWA, "mem", "-v", "1"] + extra + [fa] + fqs, stdout=f, stderr=subprocess.PIPE,
                            env=env, timeout=600)
     assert r.returncode == 0, f"bwa mem {extra} (preload={preload}) failed with {r.returncode}: {r.stderr.decode()[-2000:]}"
+    _run.last_stderr = r.stderr.decode()
     return [l for l in open(out) if not l.startswith("@PG")]
 
 
@@ -121,3 +124,8 @@ def test_pe_mate_rescue_sam_identical(genome):
     placed = sum(1 for l in ref_sam if not l.startswith("@") and int(l.split("\t")[1]) & 0x80 and not int(l.split("\t")[1]) & 0x4)
     assert placed > 900
     assert ref_sam == dut_sam
+    # ... and the DUT did it through the batched seam (mem_process_seqs -> bmh_matesw_batch), not call by call
+    import re
+    m = re.findall(r"mate rescue: (\d+) pairs, (\d+) ksw_align2 calls in (\d+) GPU rounds, (\d+) pool bytes", _run.last_stderr)
+    assert m and sum(int(x[1]) for x in m) > 100 and all(int(x[2]) <= 12 for x in m)
+    assert all(int(x[3]) <= int(x[0]) * 2 * 151 + 64 for x in m), "with the reference resident only the reads are shipped"
