@@ -51,6 +51,24 @@ def sim_reads_fast(rng, ref, n, L):
     return out
 
 
+def sim_pairs_fast(rng, ref, n, L, noisy_frac):
+    """Read pairs (FR, insert 250-450); a fraction of second mates carries 12 % substitutions, so that only mate
+    rescue (mem_matesw -> ksw_align2) can place most of them."""
+    ins = rng.integers(250, 450, size=n)
+    pos = rng.integers(0, len(ref) - 520, size=n)
+    a = np.empty((n, L), dtype=np.uint8)
+    b = np.empty((n, L), dtype=np.uint8)
+    for k in range(n):
+        f = ref[pos[k]: pos[k] + L].copy()
+        sub = rng.random(L) < 0.02
+        f[sub] = (f[sub] + rng.integers(1, 4, size=int(sub.sum()))) & 3
+        g = ref[pos[k] + ins[k] - L: pos[k] + ins[k]].copy()
+        sub = rng.random(L) < (0.12 if rng.random() < noisy_frac else 0.02)
+        g[sub] = (g[sub] + rng.integers(1, 4, size=int(sub.sum()))) & 3
+        a[k], b[k] = f, 3 - g[::-1]
+    return a, b
+
+
 def run(fa, fq, threads, batch, preload, out, ksw_dropin=True):
     env = dict(os.environ)
     if preload:
@@ -58,7 +76,7 @@ def run(fa, fq, threads, batch, preload, out, ksw_dropin=True):
         env["BMH_KSW_DROPIN"] = "1" if ksw_dropin else "0"
     t0 = time.time()
     with open(out, "w") as f:
-        p = subprocess.run([reflib.REF_BWA, "mem", "-t", str(threads), "-b", str(batch), fa, fq], stdout=f,
+        p = subprocess.run([reflib.REF_BWA, "mem", "-t", str(threads), "-b", str(batch), fa] + (fq if isinstance(fq, list) else [fq]), stdout=f,
                            stderr=subprocess.PIPE, env=env, check=True, timeout=3000)
     wall = time.time() - t0
     reads = real = 0
@@ -74,6 +92,8 @@ def main():
     ap.add_argument("--genome", type=int, default=4600000)
     ap.add_argument("--threads", default="16,64")
     ap.add_argument("--batch", type=int, default=8192)
+    ap.add_argument("--pe", action="store_true", help="paired-end reads; the DUT then also batches mate rescue on the GPU")
+    ap.add_argument("--noisy", type=float, default=0.3, help="--pe: fraction of second mates that need rescue")
     ap.add_argument("--full", action="store_true", help="also time the per-call ksw_global2 GPU drop-in (slow by design)")
     a = ap.parse_args()
     rng = np.random.default_rng(20261007)
@@ -84,9 +104,16 @@ def main():
     t0 = time.time()
     reflib.build_index(fa)
     t_index = time.time() - t0
-    reads = sim_reads_fast(rng, ref, a.reads, 150)
-    reflib.write_fastq(fq, list(reads))
-    res = {"genome_bp": a.genome, "reads": a.reads, "index_s": t_index, "runs": []}
+    if a.pe:
+        m1, m2 = sim_pairs_fast(rng, ref, a.reads // 2, 150, a.noisy)
+        fq2 = os.path.join(tmp, "reads_2.fq")
+        reflib.write_fastq(fq, list(m1), "p")
+        reflib.write_fastq(fq2, list(m2), "p")
+        fq = [fq, fq2]
+    else:
+        reads = sim_reads_fast(rng, ref, a.reads, 150)
+        reflib.write_fastq(fq, list(reads))
+    res = {"genome_bp": a.genome, "reads": a.reads, "paired": bool(a.pe), "index_s": t_index, "runs": []}
     for t in [int(x) for x in a.threads.split(",")]:
         r = run(fa, fq, t, a.batch, False, os.path.join(tmp, "ref.sam"))
         refsam = [l for l in open(os.path.join(tmp, "ref.sam")) if not l.startswith("@PG")]
