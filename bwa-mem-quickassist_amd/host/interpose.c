@@ -105,12 +105,15 @@ bmh_alnreg_v *mem_align1_core_batched(const ref_mem_opt_t *opt, const void *bwt,
 }
 
 /* =====================================================================================================================
- * mem_process_seqs() with the reference's exact signature (bwamem.h:117, bwamem.c:1297-1327), for PAIRED-END runs:
- * the same three steps as the reference -- phase 1 through the batching seam above, insert-size statistics, phase 2 --
- * with ONE addition between them: mate rescue for the whole chunk in one bmh_matesw_batch() call, after which phase 2
- * runs with MEM_F_NO_RESCUE so that mem_sam_pe skips its own per-pair rescue block (bwamem_pair.c:251-263) and goes on
- * with the vectors the batch left -- which are, element for element, what that block would have produced.
- * Single-end runs and BMH_MATESW_BATCH=0 are forwarded to the reference's own mem_process_seqs.
+ * mem_process_seqs() with the reference's exact signature (bwamem.h:117, bwamem.c:1297-1327): the same three steps as
+ * the reference -- phase 1 through the batching seam above, insert-size statistics, phase 2 -- with TWO additions
+ * between them, each one GPU-batched call for the whole chunk:
+ *   (1) pairs: mate rescue (bmh_matesw_batch), after which phase 2 runs with MEM_F_NO_RESCUE so that mem_sam_pe skips
+ *       its own per-pair rescue block (bwamem_pair.c:251-263) and goes on with the vectors the batch left -- which
+ *       are, element for element, what that block would have produced;            BMH_MATESW_BATCH=0 turns it off
+ *   (2) the global alignments of phase 2 (bmh_reg2cigar_batch), served to mem_reg2aln through an interposed
+ *       bwa_gen_cigar2 (below);                                                    BMH_CIGAR_BATCH=0 turns it off
+ * With both off the call is forwarded to the reference's own mem_process_seqs.
  */
 
 #define REF_MEM_F_PE 0x2         /* bwamem.h:14 */
@@ -158,18 +161,154 @@ static int qa_dedup(void *user, int n, bmh_alnreg_t *a) /* bmh_dedup_fn over the
 	return mem_sort_and_dedup(n, a, ((const ref_mem_opt_t *)user)->mask_level_redun);
 }
 
+/* ---- phase 2's global alignments for the whole chunk in one go ------------------------------------------------------
+ * mem_reg2aln (bwamem.c:1164-1236) is called per region from inside reference code (mem_reg2sam_se, mem_sam_pe) and is
+ * not worth restating; what it spends its time in is the loop over bwa_gen_cigar2 (bwamem.c:1193-1201).  So the shim
+ * computes that loop's FINAL outcome for every region of the chunk up front with bmh_reg2cigar_batch (<= 3 GPU rounds of
+ * ksw_global2) and serves it from a table through an interposed bwa_gen_cigar2 (bwa.h:35): the loop calls it, gets the
+ * final CIGAR+MD/score/NM at once, and -- if it asks again because score < truesc - a -- receives the same answer, sees
+ * `score == last_sc` and stops (bwamem.c:1197), i.e. it ends in exactly the state the reference ends in.  A call that is
+ * not in the table (bwa_fix_xref2's internal one, other sub-commands) goes to the reference's own bwa_gen_cigar2. */
+extern int bwa_fix_xref2(const int8_t mat[25], int o_del, int e_del, int o_ins, int e_ins, int w, const void *bns,
+                         const uint8_t *pac, uint8_t *query, int *qb, int *qe, int64_t *rb, int64_t *re); /* bwa.c:179 */
+extern void mem_mark_primary_se(const void *opt, int n, bmh_alnreg_t *a, int64_t id);                      /* bwamem.c:904 */
+extern void mem_reg2sam_se(const void *opt, const void *bns, const uint8_t *pac, ref_bseq1_t *s, bmh_alnreg_v *a,
+                           int extra_flag, const void *m);                                                 /* bwamem.c:1049 */
+
+typedef struct {
+	const uint8_t *q; /* the query bytes the entry was computed for (inside the chunk's reads) */
+	int32_t l, score, n_cigar, NM;
+	int64_t rb, re;
+	uint32_t cigar_off, md_off, md_len, used;
+} cg_entry_t;
+static struct {
+	cg_entry_t *tab; /* read-only while phase 2 runs */
+	size_t cap;
+	uint32_t *cig;
+	char *md;
+	long long hits, misses;
+} g_cg;
+
+static size_t cg_hash(int l, int64_t rb, int64_t re)
+{
+	uint64_t h = (uint64_t)rb * 0x9e3779b97f4a7c15ULL ^ (uint64_t)re * 0xc2b2ae3d27d4eb4fULL ^ (uint64_t)l * 0x165667b19e3779f9ULL;
+	return (size_t)(h ^ h >> 29);
+}
+
+typedef uint32_t *(*gen_cigar2_fn)(const int8_t *, int, int, int, int, int, int64_t, const uint8_t *, int, uint8_t *, int64_t,
+                                   int64_t, int *, int *, int *);
+
+uint32_t *bwa_gen_cigar2(const int8_t mat[25], int o_del, int e_del, int o_ins, int e_ins, int w_, int64_t l_pac,
+                         const uint8_t *pac, int l_query, uint8_t *query, int64_t rb, int64_t re, int *score, int *n_cigar,
+                         int *NM)
+{
+	static gen_cigar2_fn next;
+	if (g_cg.tab && l_query > 0) {
+		size_t k = cg_hash(l_query, rb, re) & (g_cg.cap - 1);
+		for (; g_cg.tab[k].used; k = (k + 1) & (g_cg.cap - 1)) {
+			const cg_entry_t *e = &g_cg.tab[k];
+			if (e->l == l_query && e->rb == rb && e->re == re && memcmp(e->q, query, (size_t)l_query) == 0) {
+				uint32_t *out = (uint32_t *)malloc(4 * (size_t)e->n_cigar + e->md_len + 1); /* CIGAR, then MD (bwa.c:136,161-163) */
+				memcpy(out, g_cg.cig + e->cigar_off, 4 * (size_t)e->n_cigar);
+				memcpy((char *)(out + e->n_cigar), g_cg.md + e->md_off, (size_t)e->md_len + 1);
+				*score = e->score, *n_cigar = e->n_cigar, *NM = e->NM;
+				__sync_fetch_and_add(&g_cg.hits, 1);
+				return out;
+			}
+		}
+		__sync_fetch_and_add(&g_cg.misses, 1);
+	}
+	if (!next) next = (gen_cigar2_fn)dlsym(RTLD_NEXT, "bwa_gen_cigar2");
+	if (!next) bmh_tls_die("no other bwa_gen_cigar2 is loaded", BMH_E_ARG);
+	return next(mat, o_del, e_del, o_ins, e_ins, w_, l_pac, pac, l_query, query, rb, re, score, n_cigar, NM);
+}
+
+/* every region phase 2 may turn into an alignment: score >= T (mem_reg2sam_se :1060; the pairing code picks from the same
+ * vectors).  Secondary marks are not known yet, so this is a superset; the extra alignments are cheap on the GPU. */
+static void qa_cigar_cache_build(bmh_ctx_t *ctx, const ref_mem_opt_t *opt, const ref_bntseq_head_t *bns, const uint8_t *pac,
+                                 int n, ref_bseq1_t *seqs, const bmh_alnreg_v *regs, const bmh_read_t *reads)
+{
+	size_t n_req = 0, cw = 8, mb = 16, k;
+	int i, rc;
+	bmh_cigar_req_t *reqs;
+	bmh_cigar_res_t *res;
+	for (i = 0; i < n; ++i) n_req += regs[i].n;
+	if (n_req == 0) return;
+	reqs = (bmh_cigar_req_t *)malloc(sizeof(*reqs) * n_req), n_req = 0;
+	for (i = 0; i < n; ++i) {
+		size_t j;
+		for (j = 0; j < regs[i].n; ++j) {
+			const bmh_alnreg_t *ar = &regs[i].a[j];
+			int qb = ar->qb, qe = ar->qe;
+			int64_t rb = ar->rb, re = ar->re;
+			bmh_cigar_req_t *q;
+			if (ar->score < opt->T || rb < 0 || re < 0) continue;
+			if (bwa_fix_xref2(opt->mat, opt->o_del, opt->e_del, opt->o_ins, opt->e_ins, opt->w, bns, pac, (uint8_t *)seqs[i].seq, &qb,
+			                  &qe, &rb, &re) < 0)
+				continue; /* the reference aborts on this region (bwamem.c:1183-1186); let it */
+			if (qe <= qb || re <= rb) continue;
+			q = &reqs[n_req++];
+			q->read = i, q->qb = qb, q->qe = qe, q->rb = rb, q->re = re, q->truesc = ar->truesc, q->reg_w = ar->w;
+			cw += (size_t)(qe - qb) + (size_t)(re - rb) + 2, mb += 3 * ((size_t)(qe - qb) + (size_t)(re - rb)) + 16;
+		}
+	}
+	if (n_req == 0) { free(reqs); return; }
+	res = (bmh_cigar_res_t *)malloc(sizeof(*res) * n_req);
+	g_cg.cig = (uint32_t *)malloc(4 * cw), g_cg.md = (char *)malloc(mb);
+	if ((rc = bmh_reg2cigar_batch(ctx, bns->l_pac, pac, reads, (int64_t)n_req, reqs, res, g_cg.cig, cw, g_cg.md, mb)))
+		bmh_tls_die(bmh_last_error(ctx), rc);
+	for (g_cg.cap = 64; g_cg.cap < 2 * n_req; g_cg.cap <<= 1) {}
+	g_cg.tab = (cg_entry_t *)calloc(g_cg.cap, sizeof(cg_entry_t));
+	for (k = 0; k < n_req; ++k) {
+		const bmh_cigar_req_t *q = &reqs[k];
+		size_t h;
+		if (res[k].NM < 0) continue; /* rejected (bwa.c:99): leave it to the reference */
+		for (h = cg_hash(q->qe - q->qb, q->rb, q->re) & (g_cg.cap - 1); g_cg.tab[h].used; h = (h + 1) & (g_cg.cap - 1)) {}
+		g_cg.tab[h].q = reads[q->read].seq + q->qb, g_cg.tab[h].l = q->qe - q->qb, g_cg.tab[h].rb = q->rb, g_cg.tab[h].re = q->re;
+		g_cg.tab[h].score = res[k].score, g_cg.tab[h].n_cigar = res[k].n_cigar, g_cg.tab[h].NM = res[k].NM;
+		g_cg.tab[h].cigar_off = res[k].cigar_off, g_cg.tab[h].md_off = res[k].md_off, g_cg.tab[h].md_len = res[k].md_len;
+		g_cg.tab[h].used = 1;
+	}
+	if (getenv("BMH_VERBOSE")) fprintf(stderr, "[bwamem_hip] phase 2: %zu regions through bmh_reg2cigar_batch\n", n_req);
+	free(reqs), free(res);
+}
+
+static void qa_cigar_cache_drop(void)
+{
+	if (getenv("BMH_VERBOSE") && g_cg.tab)
+		fprintf(stderr, "[bwamem_hip] phase 2: bwa_gen_cigar2 served %lld calls from the batch, %lld went to the host\n", g_cg.hits, g_cg.misses);
+	free(g_cg.tab), free(g_cg.cig), free(g_cg.md);
+	memset(&g_cg, 0, sizeof(g_cg));
+}
+
+static void qa_worker2_se(void *data, int i, int tid) /* == the SE branch of worker2, bwamem.c:1285-1289 */
+{
+	qa_worker_t *w = (qa_worker_t *)data;
+	(void)tid;
+	mem_mark_primary_se(w->opt, (int)w->regs[i].n, w->regs[i].a, w->n_processed + i);
+	mem_reg2sam_se(w->opt, w->bns, w->pac, &w->seqs[i], &w->regs[i], 0, 0);
+	free(w->regs[i].a);
+}
+
 typedef void (*process_seqs_fn)(const ref_mem_opt_t *, const void *, const ref_bntseq_head_t *, const uint8_t *, int64_t, int,
                                 ref_bseq1_t *, const bmh_pestat_t *);
 
 void mem_process_seqs(const ref_mem_opt_t *opt, const void *bwt, const ref_bntseq_head_t *bns, const uint8_t *pac,
                       int64_t n_processed, int n, ref_bseq1_t *seqs, const bmh_pestat_t *pes0)
 {
-	const char *e = getenv("BMH_MATESW_BATCH");
+	const char *e = getenv("BMH_MATESW_BATCH"), *c = getenv("BMH_CIGAR_BATCH");
+	const int pe = (opt->flag & REF_MEM_F_PE) != 0;
+	const int rescue = pe && !(opt->flag & REF_MEM_F_NO_RESCUE) && !(e && e[0] == '0');
+	const int cigars = !(c && c[0] == '0');
 	qa_worker_t w;
 	bmh_pestat_t pes[4];
 	ref_mem_opt_t opt2;
+	bmh_params_t p;
+	bmh_read_t *reads;
+	bmh_ctx_t *ctx;
 	double ctime, rtime;
-	if (!(opt->flag & REF_MEM_F_PE) || (opt->flag & REF_MEM_F_NO_RESCUE) || (e && e[0] == '0')) {
+	int i, rc;
+	if (!rescue && !cigars) { /* nothing to add: the reference's own function (its phase 1 still comes through the seam) */
 		static process_seqs_fn next;
 		if (!next) next = (process_seqs_fn)dlsym(RTLD_NEXT, "mem_process_seqs");
 		if (!next) bmh_tls_die("no other mem_process_seqs is loaded", BMH_E_ARG);
@@ -180,24 +319,25 @@ void mem_process_seqs(const ref_mem_opt_t *opt, const void *bwt, const ref_bntse
 	w.opt = opt, w.bwt = bwt, w.bns = bns, w.pac = pac, w.seqs = seqs, w.n_processed = n_processed, w.pes = pes;
 	w.regs = (bmh_alnreg_v *)malloc((size_t)n * sizeof(bmh_alnreg_v));
 	kt_for_batch(opt->n_threads, qa_worker1_batched, &w, n, opt->batch_size); /* bwamem.c:1313 */
-	if (pes0) memcpy(pes, pes0, 4 * sizeof(bmh_pestat_t));                    /* bwamem.c:1314-1317 */
-	else mem_pestat(opt, bns->l_pac, n, w.regs, pes);
-	{ /* the whole chunk's mate rescue in one call; reads are base codes by now (bwamem.c:1093-1094) */
-		bmh_params_t p;
+	if (pe) {                                                                /* bwamem.c:1314-1317 */
+		if (pes0) memcpy(pes, pes0, 4 * sizeof(bmh_pestat_t));
+		else mem_pestat(opt, bns->l_pac, n, w.regs, pes);
+	}
+	/* reads are base codes by now (bwamem.c:1093-1094) */
+	reads = (bmh_read_t *)malloc(sizeof(bmh_read_t) * (size_t)n);
+	for (i = 0; i < n; ++i) reads[i].l_seq = seqs[i].l_seq, reads[i].seq = (const uint8_t *)seqs[i].seq;
+	memset(&p, 0, sizeof(p));
+	p.o_del = opt->o_del, p.e_del = opt->e_del, p.o_ins = opt->o_ins, p.e_ins = opt->e_ins, p.zdrop = opt->zdrop;
+	p.a = opt->a, p.w = opt->w, p.pen_clip5 = opt->pen_clip5, p.pen_clip3 = opt->pen_clip3;
+	memcpy(p.mat, opt->mat, 25);
+	ctx = bmh_tls_ctx(&p);
+	{
+		const char *pr = getenv("BMH_PAC_RESIDENT");
+		if (!(pr && pr[0] == '0') && (rc = bmh_ctx_set_pac(ctx, pac, bns->l_pac))) bmh_tls_die(bmh_last_error(ctx), rc);
+	}
+	opt2 = *opt;
+	if (rescue) { /* the whole chunk's mate rescue in one call */
 		bmh_matesw_opt_t mo;
-		bmh_read_t *reads = (bmh_read_t *)malloc(sizeof(bmh_read_t) * (size_t)n);
-		bmh_ctx_t *ctx;
-		int i, rc;
-		for (i = 0; i < n; ++i) reads[i].l_seq = seqs[i].l_seq, reads[i].seq = (const uint8_t *)seqs[i].seq;
-		memset(&p, 0, sizeof(p));
-		p.o_del = opt->o_del, p.e_del = opt->e_del, p.o_ins = opt->o_ins, p.e_ins = opt->e_ins, p.zdrop = opt->zdrop;
-		p.a = opt->a, p.w = opt->w, p.pen_clip5 = opt->pen_clip5, p.pen_clip3 = opt->pen_clip3;
-		memcpy(p.mat, opt->mat, 25);
-		ctx = bmh_tls_ctx(&p);
-		{
-			const char *pr = getenv("BMH_PAC_RESIDENT");
-			if (!(pr && pr[0] == '0') && (rc = bmh_ctx_set_pac(ctx, pac, bns->l_pac))) bmh_tls_die(bmh_last_error(ctx), rc);
-		}
 		mo.pen_unpaired = opt->pen_unpaired, mo.max_matesw = opt->max_matesw, mo.min_seed_len = opt->min_seed_len, mo.rsv = 0;
 		if ((rc = bmh_matesw_batch(ctx, bns->l_pac, pac, n >> 1, reads, w.regs, pes, &mo, qa_dedup, (void *)opt, 0)))
 			bmh_tls_die(bmh_last_error(ctx), rc);
@@ -207,10 +347,14 @@ void mem_process_seqs(const ref_mem_opt_t *opt, const void *bwt, const ref_bntse
 			fprintf(stderr, "[bwamem_hip] mate rescue: %d pairs, %lld ksw_align2 calls in %lld GPU rounds, %lld pool bytes\n", n >> 1,
 			        (long long)st.ext_tasks, (long long)st.rounds, (long long)st.pool_bytes);
 		}
-		free(reads);
+		opt2.flag |= REF_MEM_F_NO_RESCUE; /* mem_sam_pe then skips bwamem_pair.c:251-263 */
 	}
-	opt2 = *opt, opt2.flag |= REF_MEM_F_NO_RESCUE, w.opt = &opt2;
-	kt_for(opt->n_threads, qa_worker2_pe, &w, n >> 1); /* bwamem.c:1319 */
+	if (cigars) qa_cigar_cache_build(ctx, opt, bns, pac, n, seqs, w.regs, reads);
+	free(reads);
+	w.opt = &opt2;
+	if (pe) kt_for(opt->n_threads, qa_worker2_pe, &w, n >> 1); /* bwamem.c:1319 */
+	else kt_for(opt->n_threads, qa_worker2_se, &w, n);
+	if (cigars) qa_cigar_cache_drop();
 	free(w.regs);
 	if (bwa_verbose >= 3)
 		fprintf(stderr, "[M::%s] Processed %d reads in %.3f CPU sec, %.3f real sec\n", __func__, n, cputime() - ctime, realtime() - rtime);

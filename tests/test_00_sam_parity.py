@@ -92,6 +92,10 @@ def test_se_sam_identical(genome, extra):
     dut_sam = _run(fa, [fq], os.path.join(tmp, "dut.sam"), extra, True)
     assert len(ref_sam) > len(reads)
     assert ref_sam == dut_sam
+    # phase 2's global alignments came from the chunk-wide batch, not from per-call ksw_global2
+    import re
+    m = re.findall(r"bwa_gen_cigar2 served (\d+) calls from the batch, (\d+) went to the host", _run.last_stderr)
+    assert m and sum(int(x[0]) for x in m) >= len(reads) // 2 and sum(int(x[1]) for x in m) == 0
 
 
 def test_pe_sam_identical(genome):
