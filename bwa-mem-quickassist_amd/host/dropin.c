@@ -59,7 +59,7 @@ int ksw_extend2(int qlen, const uint8_t *query, int tlen, const uint8_t *target,
 	p.o_del = o_del, p.e_del = e_del, p.o_ins = o_ins, p.e_ins = e_ins, p.zdrop = zdrop;
 	p.a = 1, p.w = w, p.pen_clip5 = p.pen_clip3 = end_bonus;
 	memcpy(p.mat, mat, 25);
-	ctx = bmh_tls_ctx_slot(&p, 1);
+	ctx = bmh_pool_get(&p);
 	pool = (uint8_t *)malloc((size_t)qlen + (size_t)tlen + 16);
 	memcpy(pool, query, (size_t)qlen);
 	memcpy(pool + qlen, target, (size_t)tlen);
@@ -68,6 +68,7 @@ int ksw_extend2(int qlen, const uint8_t *query, int tlen, const uint8_t *target,
 	t.q_off = 0, t.t_off = (uint64_t)qlen, t.qlen = (uint16_t)qlen, t.tlen = (uint16_t)tlen;
 	t.h0 = h0, t.w = (int16_t)w, t.end_bonus = (int16_t)end_bonus;
 	if ((rc = bmh_extend_batch(ctx, pool, (size_t)qlen + (size_t)tlen + 16, &t, 1, &r))) bmh_tls_die(bmh_last_error(ctx), rc);
+	bmh_pool_put(ctx);
 	free(pool);
 	if (qle) *qle = r.qle; /* NULL out-pointers allowed, ksw.c:470-474 */
 	if (tle) *tle = r.tle;
@@ -98,7 +99,7 @@ int ksw_global2(int qlen, const uint8_t *query, int tlen, const uint8_t *target,
 	memset(&p, 0, sizeof(p));
 	p.o_del = o_del, p.e_del = e_del, p.o_ins = o_ins, p.e_ins = e_ins, p.zdrop = 0, p.a = 1, p.w = 100;
 	memcpy(p.mat, mat, 25);
-	ctx = bmh_tls_ctx_slot(&p, 1);
+	ctx = bmh_pool_get(&p);
 	if (qlen > 65535 || tlen > 65535) bmh_tls_die("ksw_global2 drop-in: lengths out of range", BMH_E_RANGE);
 	pool = (uint8_t *)malloc((size_t)qlen + (size_t)tlen + 16);
 	memcpy(pool, query, (size_t)qlen);
@@ -111,6 +112,7 @@ int ksw_global2(int qlen, const uint8_t *query, int tlen, const uint8_t *target,
 	}
 	if ((rc = bmh_global_batch(ctx, pool, (size_t)qlen + (size_t)tlen + 16, &t, 1, &r, cig, want ? t.cigar_cap : 0)))
 		bmh_tls_die(bmh_last_error(ctx), rc);
+	bmh_pool_put(ctx);
 	free(pool);
 	if (want) {
 		if (r.n_cigar == 0) free(cig), cig = 0; /* the reference leaves a NULL pointer when nothing was pushed */
@@ -153,13 +155,14 @@ bmh_kswr_t ksw_align2(int qlen, uint8_t *query, int tlen, uint8_t *target, int m
 	memset(&p, 0, sizeof(p));
 	p.o_del = o_del, p.e_del = e_del, p.o_ins = o_ins, p.e_ins = e_ins, p.zdrop = 0, p.a = 1, p.w = 100;
 	memcpy(p.mat, mat, 25);
-	ctx = bmh_tls_ctx_slot(&p, 1);
+	ctx = bmh_pool_get(&p);
 	pool = (uint8_t *)malloc((size_t)qlen + (size_t)tlen + 16);
 	memcpy(pool, query, (size_t)qlen);
 	memcpy(pool + qlen, target, (size_t)tlen);
 	memset(&t, 0, sizeof(t));
 	t.q_off = 0, t.t_off = (uint64_t)qlen, t.qlen = (uint16_t)qlen, t.tlen = (uint32_t)tlen, t.xtra = (uint32_t)xtra;
 	if ((rc = bmh_sw_batch(ctx, pool, (size_t)qlen + (size_t)tlen + 16, &t, 1, &r))) bmh_tls_die(bmh_last_error(ctx), rc);
+	bmh_pool_put(ctx);
 	free(pool);
 	out.score = r.score, out.te = r.te, out.qe = r.qe, out.score2 = r.score2, out.te2 = r.te2, out.tb = r.tb, out.qb = r.qb;
 	return out;

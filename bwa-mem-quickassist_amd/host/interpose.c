@@ -82,7 +82,7 @@ bmh_alnreg_v *mem_align1_core_batched(const ref_mem_opt_t *opt, const void *bwt,
 	p.o_del = opt->o_del, p.e_del = opt->e_del, p.o_ins = opt->o_ins, p.e_ins = opt->e_ins, p.zdrop = opt->zdrop;
 	p.a = opt->a, p.w = opt->w, p.pen_clip5 = opt->pen_clip5, p.pen_clip3 = opt->pen_clip3;
 	memcpy(p.mat, opt->mat, 25);
-	ctx = bmh_tls_ctx(&p);
+	ctx = bmh_pool_get(&p);
 	{ /* reference resident in HBM, shared by all threads: the kernels do bns_get_seq themselves.  BMH_PAC_RESIDENT=0
 	   * falls back to host-decoded windows in the pool. */
 		const char *e = getenv("BMH_PAC_RESIDENT");
@@ -91,6 +91,7 @@ bmh_alnreg_v *mem_align1_core_batched(const ref_mem_opt_t *opt, const void *bwt,
 	ud.opt = opt, ud.l_pac = bns->l_pac, ud.pac = pac, ud.reads = reads, ud.chains = chn;
 	if ((rc = bmh_chain2aln_batch(ctx, bns->l_pac, pac, batch_size, reads, chn, pre_short, &ud, regs))) /* bwamem.c:1110 */
 		bmh_tls_die(bmh_last_error(ctx), rc);
+	bmh_pool_put(ctx);
 
 	for (b = 0; b < batch_size; ++b) { /* CPU stages after the path, unchanged: bwamem.c:1106,1112-1117 */
 		for (i = 0; i < (int)chn[b].n; ++i) free(chn[b].a[i].seeds);
@@ -179,13 +180,22 @@ typedef struct {
 	const uint8_t *q; /* the query bytes the entry was computed for (inside the chunk's reads) */
 	int32_t l, score, n_cigar, NM;
 	int64_t rb, re;
-	uint32_t cigar_off, md_off, md_len, used;
+	const uint32_t *cigar;
+	const char *md;
+	uint32_t md_len, used;
 } cg_entry_t;
+typedef struct { /* one slice of the chunk = one bmh_reg2cigar_batch call on one host thread */
+	size_t n_req;
+	bmh_cigar_req_t *reqs;
+	bmh_cigar_res_t *res;
+	uint32_t *cig;
+	char *md;
+} cg_slice_t;
 static struct {
 	cg_entry_t *tab; /* read-only while phase 2 runs */
 	size_t cap;
-	uint32_t *cig;
-	char *md;
+	cg_slice_t *slices;
+	int n_slices;
 	long long hits, misses;
 } g_cg;
 
@@ -209,8 +219,8 @@ uint32_t *bwa_gen_cigar2(const int8_t mat[25], int o_del, int e_del, int o_ins, 
 			const cg_entry_t *e = &g_cg.tab[k];
 			if (e->l == l_query && e->rb == rb && e->re == re && memcmp(e->q, query, (size_t)l_query) == 0) {
 				uint32_t *out = (uint32_t *)malloc(4 * (size_t)e->n_cigar + e->md_len + 1); /* CIGAR, then MD (bwa.c:136,161-163) */
-				memcpy(out, g_cg.cig + e->cigar_off, 4 * (size_t)e->n_cigar);
-				memcpy((char *)(out + e->n_cigar), g_cg.md + e->md_off, (size_t)e->md_len + 1);
+				memcpy(out, e->cigar, 4 * (size_t)e->n_cigar);
+				memcpy((char *)(out + e->n_cigar), e->md, (size_t)e->md_len + 1);
 				*score = e->score, *n_cigar = e->n_cigar, *NM = e->NM;
 				__sync_fetch_and_add(&g_cg.hits, 1);
 				return out;
@@ -224,61 +234,130 @@ uint32_t *bwa_gen_cigar2(const int8_t mat[25], int o_del, int e_del, int o_ins, 
 }
 
 /* every region phase 2 may turn into an alignment: score >= T (mem_reg2sam_se :1060; the pairing code picks from the same
- * vectors).  Secondary marks are not known yet, so this is a superset; the extra alignments are cheap on the GPU. */
-static void qa_cigar_cache_build(bmh_ctx_t *ctx, const ref_mem_opt_t *opt, const ref_bntseq_head_t *bns, const uint8_t *pac,
-                                 int n, ref_bseq1_t *seqs, const bmh_alnreg_v *regs, const bmh_read_t *reads)
+ * vectors).  Secondary marks are not known yet, so this is a superset; the extra alignments are cheap on the GPU.
+ * The chunk is cut into one slice per host thread: each runs its own bmh_reg2cigar_batch on its thread-local context
+ * (band inference, NM and MD are host work and scale with the threads; the GPU batches of the slices overlap). */
+typedef struct {
+	const ref_mem_opt_t *opt;
+	const ref_bntseq_head_t *bns;
+	const uint8_t *pac;
+	int n, n_slices;
+	ref_bseq1_t *seqs;
+	bmh_alnreg_v *regs;
+	const bmh_read_t *reads;
+	const bmh_params_t *params;
+	const bmh_pestat_t *pes;
+	int resident;
+} qa_slice_job_t;
+
+static bmh_ctx_t *qa_slice_ctx(const qa_slice_job_t *J)
 {
-	size_t n_req = 0, cw = 8, mb = 16, k;
+	bmh_ctx_t *ctx = bmh_pool_get(J->params);
+	int rc;
+	if (J->resident && (rc = bmh_ctx_set_pac(ctx, J->pac, J->bns->l_pac))) bmh_tls_die(bmh_last_error(ctx), rc);
+	return ctx;
+}
+
+static void qa_cigar_slice(void *data, int k, int tid)
+{
+	const qa_slice_job_t *J = (const qa_slice_job_t *)data;
+	const ref_mem_opt_t *opt = J->opt;
+	cg_slice_t *S = &g_cg.slices[k];
+	const int lo = (int)((int64_t)J->n * k / J->n_slices), hi = (int)((int64_t)J->n * (k + 1) / J->n_slices);
+	size_t n_req = 0, cw = 8, mb = 16;
 	int i, rc;
-	bmh_cigar_req_t *reqs;
-	bmh_cigar_res_t *res;
-	for (i = 0; i < n; ++i) n_req += regs[i].n;
+	(void)tid;
+	for (i = lo; i < hi; ++i) n_req += J->regs[i].n;
 	if (n_req == 0) return;
-	reqs = (bmh_cigar_req_t *)malloc(sizeof(*reqs) * n_req), n_req = 0;
-	for (i = 0; i < n; ++i) {
+	S->reqs = (bmh_cigar_req_t *)malloc(sizeof(*S->reqs) * n_req), n_req = 0;
+	for (i = lo; i < hi; ++i) {
 		size_t j;
-		for (j = 0; j < regs[i].n; ++j) {
-			const bmh_alnreg_t *ar = &regs[i].a[j];
+		for (j = 0; j < J->regs[i].n; ++j) {
+			const bmh_alnreg_t *ar = &J->regs[i].a[j];
 			int qb = ar->qb, qe = ar->qe;
 			int64_t rb = ar->rb, re = ar->re;
 			bmh_cigar_req_t *q;
 			if (ar->score < opt->T || rb < 0 || re < 0) continue;
-			if (bwa_fix_xref2(opt->mat, opt->o_del, opt->e_del, opt->o_ins, opt->e_ins, opt->w, bns, pac, (uint8_t *)seqs[i].seq, &qb,
-			                  &qe, &rb, &re) < 0)
+			if (bwa_fix_xref2(opt->mat, opt->o_del, opt->e_del, opt->o_ins, opt->e_ins, opt->w, J->bns, J->pac, (uint8_t *)J->seqs[i].seq,
+			                  &qb, &qe, &rb, &re) < 0)
 				continue; /* the reference aborts on this region (bwamem.c:1183-1186); let it */
 			if (qe <= qb || re <= rb) continue;
-			q = &reqs[n_req++];
+			q = &S->reqs[n_req++];
 			q->read = i, q->qb = qb, q->qe = qe, q->rb = rb, q->re = re, q->truesc = ar->truesc, q->reg_w = ar->w;
 			cw += (size_t)(qe - qb) + (size_t)(re - rb) + 2, mb += 3 * ((size_t)(qe - qb) + (size_t)(re - rb)) + 16;
 		}
 	}
-	if (n_req == 0) { free(reqs); return; }
-	res = (bmh_cigar_res_t *)malloc(sizeof(*res) * n_req);
-	g_cg.cig = (uint32_t *)malloc(4 * cw), g_cg.md = (char *)malloc(mb);
-	if ((rc = bmh_reg2cigar_batch(ctx, bns->l_pac, pac, reads, (int64_t)n_req, reqs, res, g_cg.cig, cw, g_cg.md, mb)))
-		bmh_tls_die(bmh_last_error(ctx), rc);
-	for (g_cg.cap = 64; g_cg.cap < 2 * n_req; g_cg.cap <<= 1) {}
-	g_cg.tab = (cg_entry_t *)calloc(g_cg.cap, sizeof(cg_entry_t));
-	for (k = 0; k < n_req; ++k) {
-		const bmh_cigar_req_t *q = &reqs[k];
-		size_t h;
-		if (res[k].NM < 0) continue; /* rejected (bwa.c:99): leave it to the reference */
-		for (h = cg_hash(q->qe - q->qb, q->rb, q->re) & (g_cg.cap - 1); g_cg.tab[h].used; h = (h + 1) & (g_cg.cap - 1)) {}
-		g_cg.tab[h].q = reads[q->read].seq + q->qb, g_cg.tab[h].l = q->qe - q->qb, g_cg.tab[h].rb = q->rb, g_cg.tab[h].re = q->re;
-		g_cg.tab[h].score = res[k].score, g_cg.tab[h].n_cigar = res[k].n_cigar, g_cg.tab[h].NM = res[k].NM;
-		g_cg.tab[h].cigar_off = res[k].cigar_off, g_cg.tab[h].md_off = res[k].md_off, g_cg.tab[h].md_len = res[k].md_len;
-		g_cg.tab[h].used = 1;
+	if (n_req == 0) return;
+	S->n_req = n_req;
+	S->res = (bmh_cigar_res_t *)malloc(sizeof(*S->res) * n_req);
+	S->cig = (uint32_t *)malloc(4 * cw), S->md = (char *)malloc(mb);
+	{
+		bmh_ctx_t *ctx = qa_slice_ctx(J);
+		if ((rc = bmh_reg2cigar_batch(ctx, J->bns->l_pac, J->pac, J->reads, (int64_t)n_req, S->reqs, S->res, S->cig, cw, S->md, mb)))
+			bmh_tls_die(bmh_last_error(ctx), rc);
+		bmh_pool_put(ctx);
 	}
-	if (getenv("BMH_VERBOSE")) fprintf(stderr, "[bwamem_hip] phase 2: %zu regions through bmh_reg2cigar_batch\n", n_req);
-	free(reqs), free(res);
+}
+
+static void qa_cigar_cache_build(qa_slice_job_t *J, int n_threads)
+{
+	size_t total = 0, k;
+	int s;
+	g_cg.n_slices = J->n_slices;
+	g_cg.slices = (cg_slice_t *)calloc((size_t)J->n_slices, sizeof(cg_slice_t));
+	kt_for(n_threads, qa_cigar_slice, J, J->n_slices);
+	for (s = 0; s < J->n_slices; ++s) total += g_cg.slices[s].n_req;
+	if (total == 0) return;
+	for (g_cg.cap = 64; g_cg.cap < 2 * total; g_cg.cap <<= 1) {}
+	g_cg.tab = (cg_entry_t *)calloc(g_cg.cap, sizeof(cg_entry_t));
+	for (s = 0; s < J->n_slices; ++s) {
+		const cg_slice_t *S = &g_cg.slices[s];
+		for (k = 0; k < S->n_req; ++k) {
+			const bmh_cigar_req_t *q = &S->reqs[k];
+			cg_entry_t *e;
+			size_t h;
+			if (S->res[k].NM < 0) continue; /* rejected (bwa.c:99): leave it to the reference */
+			for (h = cg_hash(q->qe - q->qb, q->rb, q->re) & (g_cg.cap - 1); g_cg.tab[h].used; h = (h + 1) & (g_cg.cap - 1)) {}
+			e = &g_cg.tab[h];
+			e->q = J->reads[q->read].seq + q->qb, e->l = q->qe - q->qb, e->rb = q->rb, e->re = q->re;
+			e->score = S->res[k].score, e->n_cigar = S->res[k].n_cigar, e->NM = S->res[k].NM;
+			e->cigar = S->cig + S->res[k].cigar_off, e->md = S->md + S->res[k].md_off, e->md_len = S->res[k].md_len, e->used = 1;
+		}
+	}
+	if (getenv("BMH_VERBOSE")) fprintf(stderr, "[bwamem_hip] phase 2: %zu regions through bmh_reg2cigar_batch in %d slices\n", total, J->n_slices);
 }
 
 static void qa_cigar_cache_drop(void)
 {
+	int s;
 	if (getenv("BMH_VERBOSE") && g_cg.tab)
 		fprintf(stderr, "[bwamem_hip] phase 2: bwa_gen_cigar2 served %lld calls from the batch, %lld went to the host\n", g_cg.hits, g_cg.misses);
-	free(g_cg.tab), free(g_cg.cig), free(g_cg.md);
+	for (s = 0; s < g_cg.n_slices; ++s) free(g_cg.slices[s].reqs), free(g_cg.slices[s].res), free(g_cg.slices[s].cig), free(g_cg.slices[s].md);
+	free(g_cg.tab), free(g_cg.slices);
 	memset(&g_cg, 0, sizeof(g_cg));
+}
+
+/* mate rescue, one slice of pairs per host thread */
+static long long g_msw_calls, g_msw_rounds_max, g_msw_bytes;
+static void qa_matesw_slice(void *data, int k, int tid)
+{
+	const qa_slice_job_t *J = (const qa_slice_job_t *)data;
+	const int np = J->n >> 1, lo = (int)((int64_t)np * k / J->n_slices), hi = (int)((int64_t)np * (k + 1) / J->n_slices);
+	bmh_matesw_opt_t mo;
+	bmh_driver_stats_t st;
+	bmh_ctx_t *ctx;
+	int rc;
+	(void)tid;
+	if (hi <= lo) return;
+	ctx = qa_slice_ctx(J);
+	mo.pen_unpaired = J->opt->pen_unpaired, mo.max_matesw = J->opt->max_matesw, mo.min_seed_len = J->opt->min_seed_len, mo.rsv = 0;
+	if ((rc = bmh_matesw_batch(ctx, J->bns->l_pac, J->pac, hi - lo, J->reads + 2 * lo, J->regs + 2 * lo, J->pes, &mo, qa_dedup,
+	                           (void *)J->opt, 0)))
+		bmh_tls_die(bmh_last_error(ctx), rc);
+	bmh_driver_stats(ctx, &st);
+	bmh_pool_put(ctx);
+	__sync_fetch_and_add(&g_msw_calls, st.ext_tasks), __sync_fetch_and_add(&g_msw_bytes, st.pool_bytes);
+	if (st.rounds > g_msw_rounds_max) g_msw_rounds_max = st.rounds; /* (a benign race: statistics only) */
 }
 
 static void qa_worker2_se(void *data, int i, int tid) /* == the SE branch of worker2, bwamem.c:1285-1289 */
@@ -305,9 +384,9 @@ void mem_process_seqs(const ref_mem_opt_t *opt, const void *bwt, const ref_bntse
 	ref_mem_opt_t opt2;
 	bmh_params_t p;
 	bmh_read_t *reads;
-	bmh_ctx_t *ctx;
-	double ctime, rtime;
-	int i, rc;
+	qa_slice_job_t J;
+	double ctime, rtime, t_[5];
+	int i;
 	if (!rescue && !cigars) { /* nothing to add: the reference's own function (its phase 1 still comes through the seam) */
 		static process_seqs_fn next;
 		if (!next) next = (process_seqs_fn)dlsym(RTLD_NEXT, "mem_process_seqs");
@@ -316,9 +395,11 @@ void mem_process_seqs(const ref_mem_opt_t *opt, const void *bwt, const ref_bntse
 		return;
 	}
 	ctime = cputime(), rtime = realtime();
+	t_[0] = rtime;
 	w.opt = opt, w.bwt = bwt, w.bns = bns, w.pac = pac, w.seqs = seqs, w.n_processed = n_processed, w.pes = pes;
 	w.regs = (bmh_alnreg_v *)malloc((size_t)n * sizeof(bmh_alnreg_v));
 	kt_for_batch(opt->n_threads, qa_worker1_batched, &w, n, opt->batch_size); /* bwamem.c:1313 */
+	t_[1] = realtime();
 	if (pe) {                                                                /* bwamem.c:1314-1317 */
 		if (pes0) memcpy(pes, pes0, 4 * sizeof(bmh_pestat_t));
 		else mem_pestat(opt, bns->l_pac, n, w.regs, pes);
@@ -330,30 +411,32 @@ void mem_process_seqs(const ref_mem_opt_t *opt, const void *bwt, const ref_bntse
 	p.o_del = opt->o_del, p.e_del = opt->e_del, p.o_ins = opt->o_ins, p.e_ins = opt->e_ins, p.zdrop = opt->zdrop;
 	p.a = opt->a, p.w = opt->w, p.pen_clip5 = opt->pen_clip5, p.pen_clip3 = opt->pen_clip3;
 	memcpy(p.mat, opt->mat, 25);
-	ctx = bmh_tls_ctx(&p);
 	{
 		const char *pr = getenv("BMH_PAC_RESIDENT");
-		if (!(pr && pr[0] == '0') && (rc = bmh_ctx_set_pac(ctx, pac, bns->l_pac))) bmh_tls_die(bmh_last_error(ctx), rc);
+		J.resident = !(pr && pr[0] == '0');
 	}
+	J.opt = opt, J.bns = bns, J.pac = pac, J.n = n, J.seqs = seqs, J.regs = w.regs, J.reads = reads, J.params = &p, J.pes = pes;
+	J.n_slices = opt->n_threads > 0 ? opt->n_threads : 1;
 	opt2 = *opt;
-	if (rescue) { /* the whole chunk's mate rescue in one call */
-		bmh_matesw_opt_t mo;
-		mo.pen_unpaired = opt->pen_unpaired, mo.max_matesw = opt->max_matesw, mo.min_seed_len = opt->min_seed_len, mo.rsv = 0;
-		if ((rc = bmh_matesw_batch(ctx, bns->l_pac, pac, n >> 1, reads, w.regs, pes, &mo, qa_dedup, (void *)opt, 0)))
-			bmh_tls_die(bmh_last_error(ctx), rc);
-		if (getenv("BMH_VERBOSE")) {
-			bmh_driver_stats_t st;
-			bmh_driver_stats(ctx, &st);
+	if (rescue) { /* the whole chunk's mate rescue, one bmh_matesw_batch per host thread over its share of the pairs */
+		g_msw_calls = g_msw_rounds_max = g_msw_bytes = 0;
+		kt_for(opt->n_threads, qa_matesw_slice, &J, J.n_slices);
+		if (getenv("BMH_VERBOSE"))
 			fprintf(stderr, "[bwamem_hip] mate rescue: %d pairs, %lld ksw_align2 calls in %lld GPU rounds, %lld pool bytes\n", n >> 1,
-			        (long long)st.ext_tasks, (long long)st.rounds, (long long)st.pool_bytes);
-		}
+			        g_msw_calls, g_msw_rounds_max, g_msw_bytes);
 		opt2.flag |= REF_MEM_F_NO_RESCUE; /* mem_sam_pe then skips bwamem_pair.c:251-263 */
 	}
-	if (cigars) qa_cigar_cache_build(ctx, opt, bns, pac, n, seqs, w.regs, reads);
+	t_[2] = realtime();
+	if (cigars) qa_cigar_cache_build(&J, opt->n_threads);
+	t_[3] = realtime();
 	free(reads);
 	w.opt = &opt2;
 	if (pe) kt_for(opt->n_threads, qa_worker2_pe, &w, n >> 1); /* bwamem.c:1319 */
 	else kt_for(opt->n_threads, qa_worker2_se, &w, n);
+	t_[4] = realtime();
+	if (getenv("BMH_VERBOSE"))
+		fprintf(stderr, "[bwamem_hip] chunk of %d reads: phase 1 %.3f s, pestat + mate rescue %.3f s, CIGAR batch %.3f s, phase 2 %.3f s\n", n,
+		        t_[1] - t_[0], t_[2] - t_[1], t_[3] - t_[2], t_[4] - t_[3]);
 	if (cigars) qa_cigar_cache_drop();
 	free(w.regs);
 	if (bwa_verbose >= 3)

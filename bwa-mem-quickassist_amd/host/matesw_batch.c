@@ -4,11 +4,12 @@
  *
  * What is sequential in the reference stays sequential here: every mem_matesw invocation first tests the four
  * orientations against the CURRENT content of the mate's region vector (:112-121), which earlier invocations of the
- * same pair may have changed.  So each pair is a small resumable machine {end i, hit j}; a ROUND advances every
- * unfinished pair to its next invocation that really needs Smith-Waterman, collects the up to four ksw_align2 calls of
- * that invocation (they are independent: skip[] is fixed at :112-121), runs all of them in one bmh_sw_batch, and folds
- * the results in the reference's order (:150-166 insert, :168 mem_sort_and_dedup after every orientation).
- * No speculation: exactly the calls the reference makes are made.
+ * same pair may have changed.  So each pair is a small resumable machine {end i, hit j}; a ROUND plans, per unfinished
+ * pair, its next few invocations that need Smith-Waterman (up to four ksw_align2 calls each: skip[] is fixed at
+ * :112-121), runs all of them in one bmh_sw_batch, and folds the results in the reference's order (:150-166 insert,
+ * :168 mem_sort_and_dedup after every orientation), re-deriving skip[] from the then-current vector before each
+ * invocation.  The first planned invocation of a pair is never speculative; the ones planned ahead may turn out to be
+ * skipped (their ksw_align2 results are then simply not used) -- the outcome is exactly the reference's.
  *
  * Sequences: the pool holds every read once.  A reverse-complemented mate (:130-133) is BMH_F_QREV|BMH_F_QCOMP; with
  * the reference resident on the device the window bns_get_seq would return (:143) is a BMH_F_TPAC task, otherwise it
@@ -23,14 +24,22 @@ const bmh_params_t *bmh_ctx_params_(const bmh_ctx_t *ctx);
 int bmh_ctx_has_pac_(const bmh_ctx_t *ctx, const uint8_t *pac, int64_t l_pac);
 void bmh_ctx_set_driver_stats_(bmh_ctx_t *ctx, const bmh_driver_stats_t *st);
 
+enum { LOOKAHEAD = 8 }; /* invocations planned per pair and round */
+
+typedef struct { /* one planned mem_matesw invocation: hit j of end i against the mate !i */
+	int i, j;
+	int plan[4]; /* per orientation: 0 not computed (was skipped when planned), -2 call on an empty window, -3 no call
+	                (window inverted / bridging), > 0 index+1 of its ksw_align2 result */
+	int64_t rb[4], re[4];
+} inv_t;
+
 typedef struct {
 	bmh_alnreg_v b[2];  /* hits of each end within pen_unpaired of its best, copied up front (bwamem_pair.c:252-257) */
-	int i, j;           /* next invocation: hit j of end i rescues the mate !i */
+	int i, j;           /* next invocation to fold */
 	int n;              /* sum of mem_matesw's return values */
 	int done;
-	/* the invocation in flight */
-	int skip[4], task[4];
-	int64_t rb[4], re[4];
+	int n_inv;
+	inv_t inv[LOOKAHEAD];
 } pair_t;
 
 /* mem_infer_dir, bwamem_pair.c:23-30 */
@@ -98,30 +107,41 @@ int bmh_matesw_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n_pa
 	}
 
 	for (;;) {
-		size_t n_tasks = 0, win_bytes = 0, used;
+		size_t n_tasks = 0, win_bytes = 0, used, want_tasks = 0;
 		int active = 0;
-		/* ---- advance every unfinished pair to its next invocation that needs ksw_align2 */
+		/* ---- plan: from each unfinished pair's cursor on, the next invocations that (as things stand) need ksw_align2.
+		 * The first of them is planned against exactly the state it will be folded in; the later ones are planned AHEAD
+		 * against the current state of the mate's vector, which earlier folds may still change -- ksw_align2 is pure and
+		 * its inputs (hit, orientation, mate) do not depend on that state, so a result computed ahead is THE result; the
+		 * fold below re-derives skip[] and only uses what it then really needs.  Without this, a pair with h candidate
+		 * hits would cost h GPU round trips. */
 		for (p = 0; p < n_pairs; ++p) {
 			pair_t *s = &ps[p];
-			while (!s->done) {
+			int ii, jj;
+			if (s->done) continue;
+			s->n_inv = 0;
+			for (ii = s->i, jj = s->j; ii < 2 && s->n_inv < LOOKAHEAD;) {
 				const bmh_alnreg_t *a;
 				const bmh_alnreg_v *ma;
-				int l_ms, need = 0;
+				inv_t *e;
+				int l_ms, skip[4];
 				size_t k;
-				while (s->i < 2 && !((size_t)s->j < s->b[s->i].n && s->j < o->max_matesw)) ++s->i, s->j = 0; /* :258-259 */
-				if (s->i == 2) { s->done = 1; break; }
-				a = &s->b[s->i].a[s->j], ma = &regs[2 * p + !s->i], l_ms = reads[2 * p + !s->i].l_seq;
-				for (r = 0; r < 4; ++r) s->skip[r] = pes[r].failed ? 1 : 0, s->task[r] = -1; /* :112-121 */
+				if (!((size_t)jj < s->b[ii].n && jj < o->max_matesw)) { ++ii, jj = 0; continue; } /* :258-259 */
+				a = &s->b[ii].a[jj], ma = &regs[2 * p + !ii], l_ms = reads[2 * p + !ii].l_seq;
+				for (r = 0; r < 4; ++r) skip[r] = pes[r].failed ? 1 : 0; /* :112-121 */
 				for (k = 0; k < ma->n; ++k) {
 					int64_t dist;
 					r = infer_dir(l_pac, a->rb, ma->a[k].rb, &dist);
-					if (dist >= pes[r].low && dist <= pes[r].high) s->skip[r] = 1;
+					if (dist >= pes[r].low && dist <= pes[r].high) skip[r] = 1;
 				}
-				if (s->skip[0] + s->skip[1] + s->skip[2] + s->skip[3] == 4) { ++s->j; continue; } /* :122, returns 0 */
+				if (skip[0] + skip[1] + skip[2] + skip[3] == 4) { ++jj; continue; } /* :122, returns 0 */
+				e = &s->inv[s->n_inv++];
+				e->i = ii, e->j = jj;
 				for (r = 0; r < 4; ++r) { /* :123-142 */
 					int is_rev, is_larger;
 					int64_t rb, re;
-					if (s->skip[r]) continue;
+					e->plan[r] = 0;
+					if (skip[r]) continue;
 					is_rev = (r >> 1 != (r & 1)), is_larger = !(r >> 1);
 					if (!is_rev) {
 						rb = is_larger ? a->rb + pes[r].low : a->rb - pes[r].high;
@@ -132,33 +152,27 @@ int bmh_matesw_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n_pa
 					}
 					if (rb < 0) rb = 0;
 					if (re > l_pac << 1) re = l_pac << 1;
-					s->rb[r] = rb, s->re[r] = re;
+					e->rb[r] = rb, e->re[r] = re;
 					/* bns_get_seq hands back re-rb bases unless the interval is inverted or bridges the two strands
 					 * (bntseq.c:358-375); only then does mem_matesw call ksw_align2 (:144).  An empty window is still a call:
-					 * it scores 0, inserts nothing and counts (task -2, no GPU work) */
-					if (re == rb) s->task[r] = -2;
-					else if (re > rb && (rb >= l_pac || re <= l_pac)) s->task[r] = 1, ++need, win_bytes += (size_t)(re - rb);
+					 * it scores 0, inserts nothing and counts (no GPU work) */
+					if (re == rb) e->plan[r] = -2;
+					else if (re > rb && (rb >= l_pac || re <= l_pac)) e->plan[r] = 1, ++want_tasks, win_bytes += (size_t)(re - rb);
+					else e->plan[r] = -3;
 				}
-				(void)need;
-				break; /* this invocation is in flight (possibly with zero tasks: it still runs the fold below) */
+				++jj;
 			}
-			if (!s->done) ++active;
+			++active;
 		}
 		if (!active) break;
 
 		/* ---- build the round's tasks (and, without a resident reference, its windows) */
-		{
-			size_t want_tasks = 0;
-			for (p = 0; p < n_pairs; ++p)
-				if (!ps[p].done)
-					for (r = 0; r < 4; ++r) want_tasks += ps[p].task[r] > 0;
-			if (want_tasks > task_cap) {
-				task_cap = want_tasks + want_tasks / 2 + 64;
-				free(tasks), free(res);
-				tasks = (bmh_sw_task_t *)malloc(sizeof(bmh_sw_task_t) * task_cap);
-				res = (bmh_sw_result_t *)malloc(sizeof(bmh_sw_result_t) * task_cap);
-				if (!tasks || !res) { rc = BMH_E_NOMEM; goto done; }
-			}
+		if (want_tasks > task_cap) {
+			task_cap = want_tasks + want_tasks / 2 + 64;
+			free(tasks), free(res);
+			tasks = (bmh_sw_task_t *)malloc(sizeof(bmh_sw_task_t) * task_cap);
+			res = (bmh_sw_result_t *)malloc(sizeof(bmh_sw_result_t) * task_cap);
+			if (!tasks || !res) { rc = BMH_E_NOMEM; goto done; }
 		}
 		used = reads_bytes;
 		if (first_round || !tpac) {
@@ -174,24 +188,29 @@ int bmh_matesw_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n_pa
 		}
 		for (p = 0; p < n_pairs; ++p) {
 			pair_t *s = &ps[p];
+			int v;
 			if (s->done) continue;
-			for (r = 0; r < 4; ++r) {
-				bmh_sw_task_t *t;
-				const int mate = 2 * p + !s->i, l_ms = reads[mate].l_seq, is_rev = (r >> 1 != (r & 1));
-				if (s->task[r] <= 0) continue;
-				t = &tasks[n_tasks];
-				memset(t, 0, sizeof(*t));
-				t->qlen = (uint16_t)l_ms, t->tlen = (uint32_t)(s->re[r] - s->rb[r]);
-				t->q_off = is_rev ? read_off[mate] + (uint64_t)l_ms - 1 : read_off[mate]; /* :130-133 without the copy */
-				t->flags = is_rev ? BMH_F_QREV | BMH_F_QCOMP : 0;
-				if (tpac) t->t_off = (uint64_t)s->rb[r], t->flags |= BMH_F_TPAC;
-				else {
-					fetch_window(l_pac, pac, s->rb[r], s->re[r], pool + used);
-					t->t_off = used, used += (size_t)(s->re[r] - s->rb[r]);
+			for (v = 0; v < s->n_inv; ++v) {
+				inv_t *e = &s->inv[v];
+				const int mate = 2 * p + !e->i, l_ms = reads[mate].l_seq;
+				for (r = 0; r < 4; ++r) {
+					bmh_sw_task_t *t;
+					const int is_rev = (r >> 1 != (r & 1));
+					if (e->plan[r] <= 0) continue;
+					t = &tasks[n_tasks];
+					memset(t, 0, sizeof(*t));
+					t->qlen = (uint16_t)l_ms, t->tlen = (uint32_t)(e->re[r] - e->rb[r]);
+					t->q_off = is_rev ? read_off[mate] + (uint64_t)l_ms - 1 : read_off[mate]; /* :130-133 without the copy */
+					t->flags = is_rev ? BMH_F_QREV | BMH_F_QCOMP : 0;
+					if (tpac) t->t_off = (uint64_t)e->rb[r], t->flags |= BMH_F_TPAC;
+					else {
+						fetch_window(l_pac, pac, e->rb[r], e->re[r], pool + used);
+						t->t_off = used, used += (size_t)(e->re[r] - e->rb[r]);
+					}
+					t->xtra = BMH_SW_XSUBO | BMH_SW_XSTART | (l_ms * P->a < 250 ? BMH_SW_XBYTE : 0) | (uint32_t)(o->min_seed_len * P->a); /* :147 */
+					e->plan[r] = (int)n_tasks + 1; /* 1-based index of its result */
+					++n_tasks;
 				}
-				t->xtra = BMH_SW_XSUBO | BMH_SW_XSTART | (l_ms * P->a < 250 ? BMH_SW_XBYTE : 0) | (uint32_t)(o->min_seed_len * P->a); /* :147 */
-				s->task[r] = (int)n_tasks + 1; /* 1-based index of its result */
-				++n_tasks;
 			}
 		}
 		if (n_tasks) {
@@ -205,42 +224,62 @@ int bmh_matesw_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n_pa
 			if ((rc = bmh_sw_batch(ctx, 0, 0, tasks, (int64_t)n_tasks, res))) goto done;
 		}
 
-		/* ---- fold, in the reference's order (:143-170) */
+		/* ---- fold, invocation by invocation in the reference's order (:109-175), as far as the planned results reach */
 		for (p = 0; p < n_pairs; ++p) {
 			pair_t *s = &ps[p];
-			bmh_alnreg_v *ma;
-			int n = 0, l_ms;
 			if (s->done) continue;
-			ma = &regs[2 * p + !s->i], l_ms = reads[2 * p + !s->i].l_seq;
-			for (r = 0; r < 4; ++r) {
-				if (s->skip[r]) continue;
-				if (s->task[r] > 0) {
-					const bmh_sw_result_t *aln = &res[s->task[r] - 1];
-					const int is_rev = (r >> 1 != (r & 1));
-					const int64_t rb = s->rb[r];
-					if (aln->score >= o->min_seed_len && aln->qb >= 0) { /* :150-166 */
-						bmh_alnreg_t b;
-						size_t i, tmp;
-						memset(&b, 0, sizeof(b));
-						b.qb = is_rev ? l_ms - (aln->qe + 1) : aln->qb;
-						b.qe = is_rev ? l_ms - aln->qb : aln->qe + 1;
-						b.rb = is_rev ? (l_pac << 1) - (rb + aln->te + 1) : rb + aln->tb;
-						b.re = is_rev ? (l_pac << 1) - (rb + aln->tb) : rb + aln->te + 1;
-						b.score = aln->score, b.csub = aln->score2, b.secondary = -1;
-						b.seedcov = (int32_t)((b.re - b.rb < b.qe - b.qb ? b.re - b.rb : b.qe - b.qb) >> 1);
-						push_reg(ma, &b); /* make room, then move b so that ma stays sorted by score */
-						for (i = 0; i < ma->n - 1; ++i)
-							if (ma->a[i].score < b.score) break;
-						tmp = i;
-						for (i = ma->n - 1; i > tmp; --i) ma->a[i] = ma->a[i - 1];
-						ma->a[i] = b;
-					}
-					++n;
-				} else if (s->task[r] == -2) ++n;
-				if (n) ma->n = (size_t)dedup(dedup_user, (int)ma->n, ma->a); /* :168 */
+			for (;;) {
+				const bmh_alnreg_t *a;
+				bmh_alnreg_v *ma;
+				const inv_t *e = 0;
+				int skip[4], n = 0, l_ms, v, ok = 1;
+				size_t k;
+				while (s->i < 2 && !((size_t)s->j < s->b[s->i].n && s->j < o->max_matesw)) ++s->i, s->j = 0; /* :258-259 */
+				if (s->i == 2) { s->done = 1; break; }
+				a = &s->b[s->i].a[s->j], ma = &regs[2 * p + !s->i], l_ms = reads[2 * p + !s->i].l_seq;
+				for (r = 0; r < 4; ++r) skip[r] = pes[r].failed ? 1 : 0; /* :112-121, against the vector as it is NOW */
+				for (k = 0; k < ma->n; ++k) {
+					int64_t dist;
+					r = infer_dir(l_pac, a->rb, ma->a[k].rb, &dist);
+					if (dist >= pes[r].low && dist <= pes[r].high) skip[r] = 1;
+				}
+				if (skip[0] + skip[1] + skip[2] + skip[3] == 4) { ++s->j; continue; } /* :122, returns 0 */
+				for (v = 0; v < s->n_inv; ++v)
+					if (s->inv[v].i == s->i && s->inv[v].j == s->j) e = &s->inv[v];
+				if (!e) break; /* beyond this round's plan */
+				for (r = 0; r < 4; ++r)
+					if (!skip[r] && e->plan[r] == 0) ok = 0; /* an orientation that was skipped when planned is needed after all */
+				if (!ok) break;    /* (a dedup removed the region that covered it): planned afresh in the next round */
+				for (r = 0; r < 4; ++r) {
+					if (skip[r]) continue;
+					if (e->plan[r] > 0) {
+						const bmh_sw_result_t *aln = &res[e->plan[r] - 1];
+						const int is_rev = (r >> 1 != (r & 1));
+						const int64_t rb = e->rb[r];
+						if (aln->score >= o->min_seed_len && aln->qb >= 0) { /* :150-166 */
+							bmh_alnreg_t b;
+							size_t i, tmp;
+							memset(&b, 0, sizeof(b));
+							b.qb = is_rev ? l_ms - (aln->qe + 1) : aln->qb;
+							b.qe = is_rev ? l_ms - aln->qb : aln->qe + 1;
+							b.rb = is_rev ? (l_pac << 1) - (rb + aln->te + 1) : rb + aln->tb;
+							b.re = is_rev ? (l_pac << 1) - (rb + aln->tb) : rb + aln->te + 1;
+							b.score = aln->score, b.csub = aln->score2, b.secondary = -1;
+							b.seedcov = (int32_t)((b.re - b.rb < b.qe - b.qb ? b.re - b.rb : b.qe - b.qb) >> 1);
+							push_reg(ma, &b); /* make room, then move b so that ma stays sorted by score */
+							for (i = 0; i < ma->n - 1; ++i)
+								if (ma->a[i].score < b.score) break;
+							tmp = i;
+							for (i = ma->n - 1; i > tmp; --i) ma->a[i] = ma->a[i - 1];
+							ma->a[i] = b;
+						}
+						++n;
+					} else if (e->plan[r] == -2) ++n;
+					if (n) ma->n = (size_t)dedup(dedup_user, (int)ma->n, ma->a); /* :168 */
+				}
+				s->n += n;
+				++s->j;
 			}
-			s->n += n;
-			++s->j;
 		}
 	}
 	if (n_sw)

@@ -1,13 +1,21 @@
 /* tls_ctx.c -- see tls_ctx.h */
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include "tls_ctx.h"
 
-static __thread bmh_ctx_t *tls_ctx_[2];
-static __thread bmh_params_t tls_params_[2];
-static __thread int tls_have_[2];
+typedef struct {
+	bmh_ctx_t *ctx;
+	bmh_params_t params;
+	int have, busy;
+} slot_t;
+
+#define BMH_POOL_MAX 1024
+static slot_t g_slots[BMH_POOL_MAX];
+static int g_n;
+static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
 
 void bmh_tls_die(const char *msg, int code)
 {
@@ -15,18 +23,37 @@ void bmh_tls_die(const char *msg, int code)
 	abort();
 }
 
-bmh_ctx_t *bmh_tls_ctx_slot(const bmh_params_t *p, int slot)
+bmh_ctx_t *bmh_pool_get(const bmh_params_t *p)
 {
-	int rc;
-	if (!tls_ctx_[slot]) {
+	slot_t *s = 0;
+	int i, rc;
+	pthread_mutex_lock(&g_mu);
+	for (i = 0; i < g_n && !s; ++i) /* prefer an idle context that already carries these parameters */
+		if (!g_slots[i].busy && g_slots[i].have && memcmp(&g_slots[i].params, p, sizeof(*p)) == 0) s = &g_slots[i];
+	for (i = 0; i < g_n && !s; ++i)
+		if (!g_slots[i].busy) s = &g_slots[i];
+	if (!s) {
+		if (g_n == BMH_POOL_MAX) bmh_tls_die("context pool exhausted", BMH_E_NOMEM);
+		s = &g_slots[g_n++];
+	}
+	s->busy = 1;
+	pthread_mutex_unlock(&g_mu);
+	if (!s->ctx) {
 		const char *dev = getenv("BMH_DEVICE");
-		if ((rc = bmh_ctx_create(&tls_ctx_[slot], dev ? atoi(dev) : 0))) bmh_tls_die("cannot create a GPU context", rc);
+		if ((rc = bmh_ctx_create(&s->ctx, dev ? atoi(dev) : 0))) bmh_tls_die("cannot create a GPU context", rc);
 	}
-	if (!tls_have_[slot] || memcmp(&tls_params_[slot], p, sizeof(*p)) != 0) {
-		if ((rc = bmh_ctx_set_params(tls_ctx_[slot], p))) bmh_tls_die(bmh_last_error(tls_ctx_[slot]), rc);
-		tls_params_[slot] = *p, tls_have_[slot] = 1;
+	if (!s->have || memcmp(&s->params, p, sizeof(*p)) != 0) {
+		if ((rc = bmh_ctx_set_params(s->ctx, p))) bmh_tls_die(bmh_last_error(s->ctx), rc);
+		s->params = *p, s->have = 1;
 	}
-	return tls_ctx_[slot];
+	return s->ctx;
 }
 
-bmh_ctx_t *bmh_tls_ctx(const bmh_params_t *p) { return bmh_tls_ctx_slot(p, 0); }
+void bmh_pool_put(bmh_ctx_t *ctx)
+{
+	int i;
+	pthread_mutex_lock(&g_mu);
+	for (i = 0; i < g_n; ++i)
+		if (g_slots[i].ctx == ctx) g_slots[i].busy = 0;
+	pthread_mutex_unlock(&g_mu);
+}

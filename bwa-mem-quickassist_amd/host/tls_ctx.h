@@ -1,13 +1,15 @@
-/* tls_ctx.h -- one lazily created GPU context per host thread for the reference-side shims
- * (the reference calls phase 1 from n_threads pthreads on disjoint reads, bwamem.c:1313). */
+/* tls_ctx.h -- GPU contexts for the reference-side shims.
+ * The reference runs phase 1 / phase 2 on n_threads pthreads that are created and joined PER CHUNK (kthread.c:51-52),
+ * so thread-local contexts would be created and lost once per chunk and thread.  Contexts therefore live in a process-
+ * wide pool: a caller takes one for the duration of a call and gives it back.  That also makes the shims re-entrant:
+ * the reference calls ksw_align2 (via mem_chain2aln_short) from INSIDE the batched phase-1 call, and simply gets a
+ * second context. */
 #ifndef BMH_TLS_CTX_H
 #define BMH_TLS_CTX_H
 #include "../../include/bwamem_hip.h"
 
-/* context of the calling thread with `p` installed (device = $BMH_DEVICE, default 0); aborts on failure */
-bmh_ctx_t *bmh_tls_ctx(const bmh_params_t *p);
-/* slot 0: the batched seam (interpose.c); slot 1: the per-call drop-ins, which the reference may call from INSIDE a
- * batched call (mem_chain2aln_short -> ksw_align2 runs in the driver's pre-callback) and must not disturb it */
-bmh_ctx_t *bmh_tls_ctx_slot(const bmh_params_t *p, int slot);
+/* an idle context with `p` installed (device = $BMH_DEVICE, default 0); aborts on failure */
+bmh_ctx_t *bmh_pool_get(const bmh_params_t *p);
+void bmh_pool_put(bmh_ctx_t *ctx);
 void bmh_tls_die(const char *msg, int code);
 #endif

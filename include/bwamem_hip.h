@@ -304,8 +304,9 @@ int bmh_sw_batch_device(bmh_ctx_t *ctx, const uint8_t *d_pool, const bmh_sw_task
  *                            post-processing outside this path, so the reference's own function is passed in
  *   n_sw[p] (nullable)       the sum of mem_matesw's return values for pair p
  * Each mem_matesw invocation tests its four orientations against the current state of the mate's vector, so the
- * invocations of one pair are sequential; the driver runs them as rounds -- one invocation per unfinished pair and
- * round, its up to four ksw_align2 calls as one GPU batch over all pairs.  Exactly the reference's calls are made.
+ * invocations of one pair are sequential; the driver runs them as rounds -- per unfinished pair its next few
+ * invocations (planned ahead against the current state, re-checked when folded), their ksw_align2 calls as one GPU
+ * batch over all pairs.  The outcome is exactly the reference's; a call planned ahead may go unused.
  * With the reference resident (bmh_ctx_set_pac, same pac pointer) the windows are BMH_F_TPAC tasks and the
  * reverse-complemented mate is BMH_F_QREV|BMH_F_QCOMP: the pool holds every read once and nothing else. */
 typedef struct bmh_pestat { /* mem_pestat_t, bwamem.h:66-70 */

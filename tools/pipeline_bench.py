@@ -74,6 +74,7 @@ def run(fa, fq, threads, batch, preload, out, ksw_dropin=True):
     if preload:
         env["LD_PRELOAD"] = load_package().DROPIN_PATH
         env["BMH_KSW_DROPIN"] = "1" if ksw_dropin else "0"
+        env["BMH_VERBOSE"] = "1"
     t0 = time.time()
     with open(out, "w") as f:
         p = subprocess.run([reflib.REF_BWA, "mem", "-t", str(threads), "-b", str(batch), fa] + (fq if isinstance(fq, list) else [fq]), stdout=f,
@@ -83,7 +84,8 @@ def run(fa, fq, threads, batch, preload, out, ksw_dropin=True):
     for m in re.finditer(r"Processed (\d+) reads in ([\d.]+) CPU sec, ([\d.]+) real sec", p.stderr.decode()):
         reads += int(m.group(1))
         real += float(m.group(3))
-    return {"reads": reads, "process_seqs_real_s": real, "reads_per_s": reads / real if real else None, "wall_s": wall}
+    shim = [l for l in p.stderr.decode().splitlines() if l.startswith("[bwamem_hip]")]
+    return {"reads": reads, "shim": shim[:12], "process_seqs_real_s": real, "reads_per_s": reads / real if real else None, "wall_s": wall}
 
 
 def main():
