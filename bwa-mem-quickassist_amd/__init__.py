@@ -37,6 +37,16 @@ SW_TASK = np.dtype([("q_off", "<u8"), ("t_off", "<u8"), ("tlen", "<u4"), ("qlen"
 SW_RES = np.dtype([("score", "<i4"), ("te", "<i4"), ("qe", "<i4"), ("score2", "<i4"), ("te2", "<i4"),
                    ("tb", "<i4"), ("qb", "<i4"), ("rsv", "<i4")])
 KSW_XBYTE, KSW_XSTOP, KSW_XSUBO, KSW_XSTART = 0x10000, 0x20000, 0x40000, 0x80000  # reference ksw.h:6-9
+SMEM_INTV = np.dtype([("x0", "<u8"), ("x1", "<u8"), ("x2", "<u8"), ("info", "<u8")])
+SMEM_CALL = np.dtype([("x", "<i4"), ("min_intv", "<i4"), ("ret", "<i4"), ("n", "<i4"), ("first", "<u4"), ("rsv", "<u4")])
+SMEM_OPT = np.dtype([("min_seed_len", "<i4"), ("split_len", "<i4"), ("split_width", "<i4"), ("start_width", "<i4")])
+
+
+class _Bwt(C.Structure):  # bmh_bwt_t
+    _fields_ = [("primary", C.c_uint64), ("L2", C.c_uint64 * 5), ("seq_len", C.c_uint64), ("bwt_size", C.c_uint64),
+                ("bwt", C.c_void_p), ("sa_intv", C.c_int32), ("n_sa", C.c_uint64), ("sa", C.c_void_p)]
+
+
 PESTAT = np.dtype([("low", "<i4"), ("high", "<i4"), ("failed", "<i4"), ("pad", "<i4"), ("avg", "<f8"), ("std", "<f8")])
 MATESW_OPT = np.dtype([("pen_unpaired", "<i4"), ("max_matesw", "<i4"), ("min_seed_len", "<i4"), ("rsv", "<i4")])
 PARAMS = np.dtype([("o_del", "<i4"), ("e_del", "<i4"), ("o_ins", "<i4"), ("e_ins", "<i4"),
@@ -104,6 +114,10 @@ def lib():
         L.bmh_upload_pool.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.bmh_extend_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int64, C.c_void_p]
         L.bmh_extend_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.bmh_ctx_set_bwt.argtypes = [C.c_void_p, C.c_void_p]
+        L.bmh_smem_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                     C.c_void_p, C.c_size_t]
+        L.bmh_sa_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.bmh_matesw_batch.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.bmh_sw_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int64, C.c_void_p]
@@ -223,6 +237,50 @@ class Context:
 
     def sw_batch_device(self, d_pool, d_tasks, n, d_res):
         self._check(lib().bmh_sw_batch_device(self._h, C.c_void_p(d_pool), C.c_void_p(d_tasks), int(n), C.c_void_p(d_res)))
+
+    def set_bwt(self, primary, L2, seq_len, bwt_words, sa_intv, sa):
+        """Make the FM-index resident (the arrays of the reference's bwt_t, bwt.h:45-57)."""
+        bw = np.ascontiguousarray(bwt_words, dtype=np.uint32)
+        sa = np.ascontiguousarray(sa, dtype=np.uint64)
+        self._bwt_keep = (bw, sa)
+        b = _Bwt()
+        b.primary, b.seq_len, b.bwt_size, b.sa_intv, b.n_sa = int(primary), int(seq_len), len(bw), int(sa_intv), len(sa)
+        for i in range(5):
+            b.L2[i] = int(L2[i])
+        b.bwt, b.sa = bw.ctypes.data, sa.ctypes.data
+        self._check(lib().bmh_ctx_set_bwt(self._h, C.byref(b)))
+
+    def smem_batch(self, opt, reads):
+        """The bwt_smem1 calls of smem_next2's iteration for every read (reference bwt.c:288, bwamem.c:118).
+        Returns per read (SMEM_CALL[], SMEM_INTV[])."""
+        n = len(reads)
+        opt = np.ascontiguousarray(opt, dtype=SMEM_OPT)
+        keep = []
+        c_reads = (_Read * max(n, 1))()
+        tot = 0
+        for k, r in enumerate(reads):
+            r = np.ascontiguousarray(r, dtype=np.uint8)
+            keep.append(r)
+            c_reads[k].l_seq, c_reads[k].seq = len(r), r.ctypes.data
+            tot += len(r)
+        call_cap, intv_cap = 2 * tot + 16, 64 * tot + 1024
+        call_off = np.zeros(n + 1, dtype=np.uint32)
+        intv_off = np.zeros(n + 1, dtype=np.uint64)
+        calls = np.zeros(call_cap, dtype=SMEM_CALL)
+        intv = np.zeros(intv_cap, dtype=SMEM_INTV)
+        self._check(lib().bmh_smem_batch(self._h, _ptr(opt), n, C.cast(c_reads, C.c_void_p), _ptr(call_off), _ptr(calls),
+                                         C.c_size_t(call_cap), _ptr(intv_off), _ptr(intv), C.c_size_t(intv_cap)))
+        out = []
+        for r in range(n):
+            out.append((calls[call_off[r]:call_off[r + 1]].copy(), intv[int(intv_off[r]):int(intv_off[r + 1])].copy()))
+        return out
+
+    def sa_batch(self, ks):
+        """N x bwt_sa (reference bwt.c:85)."""
+        ks = np.ascontiguousarray(ks, dtype=np.uint64)
+        pos = np.zeros(len(ks), dtype=np.uint64)
+        self._check(lib().bmh_sa_batch(self._h, _ptr(ks), len(ks), _ptr(pos)))
+        return pos
 
     def matesw_batch(self, l_pac, pac, reads, regs, pes, opt, dedup):
         """Batched mate rescue (reference bwamem_pair.c:251-263 over mem_matesw :109-175) for len(reads)//2 pairs.

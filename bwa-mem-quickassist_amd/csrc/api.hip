@@ -128,6 +128,7 @@ int bmh_ctx_create(bmh_ctx_t **out, int device)
 }
 
 static void pac_release(bmh_ctx_t *ctx);
+void free_bwt_binding(void *p); // fmindex.hip
 
 int bmh_ctx_destroy(bmh_ctx_t *ctx)
 {
@@ -137,6 +138,7 @@ int bmh_ctx_destroy(bmh_ctx_t *ctx)
 	free_buf(ctx->d_pool), free_buf(ctx->d_tasks), free_buf(ctx->d_res), free_buf(ctx->d_order);
 	free_buf(ctx->d_cigar), free_buf(ctx->d_scratch), free_buf(ctx->d_bins), free_buf(ctx->d_zslab), free_buf(ctx->d_sw), free_buf(ctx->d_swrm);
 	pac_release(ctx);
+	if (ctx->bwt_bind) free_bwt_binding(ctx->bwt_bind);
 	if (ctx->d_err) (void)hipFree(ctx->d_err);
 	if (ctx->h_err) (void)hipHostFree(ctx->h_err);
 	if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);

@@ -1,0 +1,407 @@
+// fmindex.hip -- FM-index queries of BWA-MEM's seeding stage on the device (first slice):
+//   smem_kernel  one lane per read: the bwt_smem1 calls (reference bwa-0.7.8/bwt.c:288-347) of smem_next2's iteration
+//                (bwamem.c:118-162) over bwt_extend (bwt.c:261-274) / bwt_occ4 (bwt.c:159-177)
+//   sa_kernel    one lane per suffix-array entry: bwt_sa (bwt.c:85-95) over bwt_invPsi (:52-58) / bwt_occ (:107-129)
+// The index is the reference's own: the BWT with its interleaved occurrence counts (one 64-byte block per 128
+// symbols: 4 x u64 counts + 8 words of 2-bit symbols, bwt.h:63-64) and the sampled suffix array, resident in HBM.
+// Every occurrence query touches exactly one such block; counting is done with v_bcnt on equality masks instead of
+// the reference's 256-entry byte table (same numbers).  This stage is the one part of the pipeline that is bound by
+// random memory access rather than by instruction issue.
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "bmh_ctx.h"
+#include "bmh_device.h"
+
+namespace bmh {
+
+struct DevBwt {
+	uint64_t primary, L2[5], seq_len;
+	const uint32_t *bwt;
+	const uint64_t *sa;
+	uint64_t sa_mask; // sa_intv - 1
+	int sa_shift;     // log2(sa_intv)
+};
+
+struct Intv { // == bwtintv_t
+	uint64_t x0, x1, x2, info;
+};
+
+// symbols equal to c among the first n (0..16) symbols of a packed word (symbol 0 in the top two bits)
+__device__ __forceinline__ int fm_count(uint32_t w, uint32_t pat, uint32_t keep)
+{
+	const uint32_t x = w ^ pat; // a symbol equals c <=> both of its bits are now 0
+	return __popc(~(x | x >> 1) & 0x55555555u & keep);
+}
+
+// bwt_occ4, bwt.c:159-177
+__device__ __forceinline__ void fm_occ4(const DevBwt &B, uint64_t k, uint64_t cnt[4])
+{
+	if (k == (uint64_t)-1) { cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0; return; }
+	k -= (k >= B.primary); // the sentinel is not stored
+	const uint4 *blk = (const uint4 *)(B.bwt + ((k >> 7) << 4));
+	const uint4 c0 = blk[0], c1 = blk[1], w0 = blk[2], w1 = blk[3];
+	cnt[0] = (uint64_t)c0.y << 32 | c0.x, cnt[1] = (uint64_t)c0.w << 32 | c0.z;
+	cnt[2] = (uint64_t)c1.y << 32 | c1.x, cnt[3] = (uint64_t)c1.w << 32 | c1.z;
+	const uint32_t w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+	const int full = (int)((k & 127) >> 4), rest = (int)(k & 15) + 1;
+	int n[4] = {0, 0, 0, 0};
+#pragma unroll
+	for (int j = 0; j < 8; ++j) {
+		const uint32_t keep = j < full ? 0xffffffffu : j == full ? 0xffffffffu << (32 - 2 * rest) : 0u;
+#pragma unroll
+		for (int c = 0; c < 4; ++c) n[c] += fm_count(w[j], (uint32_t)c * 0x55555555u, keep);
+	}
+#pragma unroll
+	for (int c = 0; c < 4; ++c) cnt[c] += (uint64_t)n[c];
+}
+
+// bwt_extend, bwt.c:261-274
+__device__ __forceinline__ void fm_extend(const DevBwt &B, const Intv &ik, Intv ok[4], bool is_back)
+{
+	uint64_t tk[4], tl[4];
+	const uint64_t a = is_back ? ik.x0 : ik.x1, b = is_back ? ik.x1 : ik.x0; // a = x[!is_back], b = x[is_back]
+	fm_occ4(B, a - 1, tk);
+	fm_occ4(B, a - 1 + ik.x2, tl);
+	uint64_t na[4], nb[4];
+#pragma unroll
+	for (int i = 0; i < 4; ++i) na[i] = B.L2[i] + 1 + tk[i], ok[i].x2 = tl[i] - tk[i];
+	nb[3] = b + (a <= B.primary && a + ik.x2 - 1 >= B.primary);
+	nb[2] = nb[3] + ok[3].x2, nb[1] = nb[2] + ok[2].x2, nb[0] = nb[1] + ok[1].x2;
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		ok[i].x0 = is_back ? na[i] : nb[i];
+		ok[i].x1 = is_back ? nb[i] : na[i];
+	}
+}
+
+// a lane's three interval stacks live in a slab laid out [entry][lane]: lanes of a wave walking their stacks in step
+// touch adjacent 32-byte records
+struct Stack {
+	Intv *base;
+	__device__ __forceinline__ Intv &operator[](int j) const { return base[(size_t)j * 64]; }
+};
+
+// bwt_smem1, bwt.c:288-347.  mem receives the result in reference order; returns the next start; *n_mem = mem->n.
+__device__ int fm_smem1(const DevBwt &B, int len, const uint8_t *q, int x, int min_intv, Stack prev, Stack curr, Stack mem,
+                        int *n_mem)
+{
+	*n_mem = 0;
+	if (q[x] > 3) return x + 1;
+	if (min_intv < 1) min_intv = 1;
+	Intv ik, ok[4];
+	int np, nc = 0, nm = 0, i;
+	{
+		const int c = q[x];
+		ik.x0 = B.L2[c] + 1, ik.x2 = B.L2[c + 1] - B.L2[c], ik.x1 = B.L2[3 - c] + 1, ik.info = (uint64_t)x + 1; // bwt_set_intv
+	}
+	for (i = x + 1; i < len; ++i) { // forward search
+		if (q[i] < 4) {
+			const int c = 3 - q[i];
+			fm_extend(B, ik, ok, false);
+			const Intv o = c == 0 ? ok[0] : c == 1 ? ok[1] : c == 2 ? ok[2] : ok[3];
+			if (o.x2 != ik.x2) {
+				curr[nc++] = ik;
+				if (o.x2 < (uint64_t)min_intv) break;
+			}
+			ik = o, ik.info = (uint64_t)i + 1;
+		} else {
+			curr[nc++] = ik;
+			break;
+		}
+	}
+	if (i == len) curr[nc++] = ik;
+	for (int j = 0; j < nc >> 1; ++j) { // longer matches first
+		const Intv t = curr[nc - 1 - j];
+		curr[nc - 1 - j] = curr[j], curr[j] = t;
+	}
+	const int ret = (int)curr[0].info;
+	{ const Stack t = curr; curr = prev, prev = t; }
+	np = nc;
+	for (i = x - 1; i >= -1; --i) { // backward search for MEMs
+		const int c = i < 0 ? -1 : q[i] < 4 ? q[i] : -1;
+		nc = 0;
+		for (int j = 0; j < np; ++j) {
+			const Intv p = prev[j];
+			fm_extend(B, p, ok, true);
+			const Intv o = c <= 0 ? ok[0] : c == 1 ? ok[1] : c == 2 ? ok[2] : ok[3];
+			if (c < 0 || o.x2 < (uint64_t)min_intv) {
+				if (nc == 0 && (nm == 0 || (uint64_t)(i + 1) < mem[nm - 1].info >> 32)) {
+					Intv m = p;
+					m.info |= (uint64_t)(i + 1) << 32;
+					mem[nm++] = m;
+				}
+			} else if (nc == 0 || o.x2 != curr[nc - 1].x2) {
+				Intv m = o;
+				m.info = p.info;
+				curr[nc++] = m;
+			}
+		}
+		if (nc == 0) break;
+		{ const Stack t = curr; curr = prev, prev = t; }
+		np = nc;
+	}
+	*n_mem = nm; // (still in reverse order; the caller writes it out back to front)
+	return ret;
+}
+
+__global__ __launch_bounds__(64) void smem_kernel(DevBwt B, const uint8_t *__restrict__ pool,
+                                                  const uint64_t *__restrict__ read_off, const int *__restrict__ read_len,
+                                                  int n_reads, bmh_smem_opt_t O, Intv *scratch, int lcap,
+                                                  bmh_smem_call_t *calls, uint32_t *call_read, unsigned long long *cursors,
+                                                  unsigned long long call_cap, Intv *intv, unsigned long long intv_cap,
+                                                  int *overflow)
+{
+	const int lane = threadIdx.x;
+	Intv *slab = scratch + (size_t)blockIdx.x * 3 * (size_t)lcap * 64 + lane;
+	const Stack s0{slab}, s1{slab + (size_t)lcap * 64}, sm{slab + 2 * (size_t)lcap * 64};
+	for (long long r = (long long)blockIdx.x * 64 + lane; r < n_reads; r += (long long)gridDim.x * 64) {
+		const uint8_t *q = pool + read_off[r];
+		const int len = read_len[r];
+		const int split_len = min(O.split_len, len); // bwamem.c:213
+		int start = 0, seq = 0;
+		while (start < len) { // smem_next2, bwamem.c:118-162
+			while (start < len && q[start] > 3) ++start;
+			if (start == len) break;
+			int n, n2 = 0, x2 = 0, mi2 = 0, ret2 = 0;
+			const int x1 = start;
+			const int ret = fm_smem1(B, len, q, x1, O.start_width, s0, s1, sm, &n);
+			start = ret;
+			// the longest match, first of equals (sm holds them back to front)
+			int mx = 0, mxk = 0;
+			for (int i = 0; i < n; ++i) {
+				const Intv v = sm[n - 1 - i];
+				const int l = (int)((uint32_t)v.info - (uint32_t)(v.info >> 32));
+				if (mx < l) mx = l, mxk = n - 1 - i;
+			}
+			// write call 1
+			unsigned long long ci = atomicAdd(&cursors[0], 1ull), base = atomicAdd(&cursors[1], (unsigned long long)n);
+			if (ci < call_cap && base + n <= intv_cap) {
+				bmh_smem_call_t c;
+				c.x = x1, c.min_intv = O.start_width, c.ret = ret, c.n = n, c.first = (uint32_t)base, c.rsv = (uint32_t)seq;
+				calls[ci] = c, call_read[ci] = (uint32_t)r;
+				for (int i = 0; i < n; ++i) intv[base + i] = sm[n - 1 - i];
+			} else atomicExch(overflow, 1);
+			++seq;
+			bool split = false;
+			if (n > 0 && split_len > 0 && mx >= split_len) {
+				const Intv v = sm[mxk];
+				if (v.x2 <= (uint64_t)O.split_width) split = true, x2 = (int)(((uint32_t)v.info + (uint32_t)(v.info >> 32)) >> 1), mi2 = (int)v.x2 + 1;
+			}
+			if (split) { // re-seeding from the middle of the longest match
+				ret2 = fm_smem1(B, len, q, x2, mi2, s0, s1, sm, &n2);
+				ci = atomicAdd(&cursors[0], 1ull), base = atomicAdd(&cursors[1], (unsigned long long)n2);
+				if (ci < call_cap && base + n2 <= intv_cap) {
+					bmh_smem_call_t c;
+					c.x = x2, c.min_intv = mi2, c.ret = ret2, c.n = n2, c.first = (uint32_t)base, c.rsv = (uint32_t)seq;
+					calls[ci] = c, call_read[ci] = (uint32_t)r;
+					for (int i = 0; i < n2; ++i) intv[base + i] = sm[n2 - 1 - i];
+				} else atomicExch(overflow, 1);
+				++seq;
+			}
+		}
+	}
+}
+
+// bwt_sa, bwt.c:85-95
+__global__ void sa_kernel(DevBwt B, const uint64_t *__restrict__ ks, long long n, uint64_t *__restrict__ pos)
+{
+	for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long long)gridDim.x * blockDim.x) {
+		uint64_t k = ks[t], sa = 0;
+		while (k & B.sa_mask) {
+			const uint64_t x = k - (k > B.primary);
+			const int c = (int)(B.bwt[((x >> 7) << 4) + 8 + ((x & 127) >> 4)] >> ((~x & 15) << 1) & 3); // bwt_B0, bwt.h:70
+			++sa;
+			if (k == B.primary) k = 0; // bwt_invPsi, bwt.c:57
+			else {
+				uint64_t cnt[4];
+				if (k == B.seq_len) k = B.L2[c] + (B.L2[c + 1] - B.L2[c]); // bwt_occ's first special case, bwt.c:112
+				else {
+					fm_occ4(B, k, cnt);
+					k = B.L2[c] + (c == 0 ? cnt[0] : c == 1 ? cnt[1] : c == 2 ? cnt[2] : cnt[3]);
+				}
+			}
+		}
+		pos[t] = sa + B.sa[k >> B.sa_shift];
+	}
+}
+
+// ---- host side: one resident copy of the index per (device, host arrays), shared by all contexts ----
+struct BwtShare {
+	int device;
+	const uint32_t *h_bwt;
+	const uint64_t *h_sa;
+	void *d_bwt, *d_sa;
+	DevBwt dev;
+	int refs;
+};
+static std::mutex g_bwt_mu;
+static std::vector<BwtShare> g_bwts;
+
+} // namespace bmh
+
+using namespace bmh;
+
+struct bmh_bwt_binding { // hangs off the context (opaque pointer in bmh_ctx)
+	DevBwt dev;
+	const uint32_t *h_bwt;
+};
+
+extern "C" void free_bwt_binding(void *p) { delete (bmh_bwt_binding *)p; }
+
+extern "C" {
+
+int bmh_ctx_set_bwt(bmh_ctx_t *ctx, const bmh_bwt_t *b)
+{
+	if (!ctx || !b || !b->bwt || !b->sa || b->sa_intv < 1 || (b->sa_intv & (b->sa_intv - 1))) return BMH_E_ARG;
+	BMH_HIP(ctx, hipSetDevice(ctx->device));
+	std::lock_guard<std::mutex> lk(g_bwt_mu);
+	if (ctx->bwt_bind && ((bmh_bwt_binding *)ctx->bwt_bind)->h_bwt == b->bwt) return BMH_OK;
+	BwtShare *s = nullptr;
+	for (auto &e : g_bwts)
+		if (e.device == ctx->device && e.h_bwt == b->bwt && e.h_sa == b->sa) s = &e;
+	if (!s) {
+		BwtShare n{};
+		n.device = ctx->device, n.h_bwt = b->bwt, n.h_sa = b->sa;
+		const size_t bw = (size_t)b->bwt_size * 4 + 64, sb = (size_t)b->n_sa * 8 + 64;
+		if (hipMalloc(&n.d_bwt, bw) != hipSuccess || hipMalloc(&n.d_sa, sb) != hipSuccess) {
+			(void)hipGetLastError();
+			ctx->last_error = "hipMalloc for the FM-index failed";
+			return BMH_E_NOMEM;
+		}
+		if (hipMemcpy(n.d_bwt, b->bwt, (size_t)b->bwt_size * 4, hipMemcpyHostToDevice) != hipSuccess ||
+		    hipMemcpy(n.d_sa, b->sa, (size_t)b->n_sa * 8, hipMemcpyHostToDevice) != hipSuccess) {
+			ctx->last_error = "uploading the FM-index failed";
+			return BMH_E_HIP;
+		}
+		n.dev.primary = b->primary, n.dev.seq_len = b->seq_len;
+		for (int i = 0; i < 5; ++i) n.dev.L2[i] = b->L2[i];
+		n.dev.bwt = (const uint32_t *)n.d_bwt, n.dev.sa = (const uint64_t *)n.d_sa;
+		n.dev.sa_mask = (uint64_t)b->sa_intv - 1, n.dev.sa_shift = __builtin_ctz((unsigned)b->sa_intv);
+		n.refs = 0;
+		g_bwts.push_back(n);
+		s = &g_bwts.back();
+	}
+	++s->refs; // (kept for the life of the process: the index is as immutable as the reference)
+	if (!ctx->bwt_bind) ctx->bwt_bind = new bmh_bwt_binding();
+	((bmh_bwt_binding *)ctx->bwt_bind)->dev = s->dev, ((bmh_bwt_binding *)ctx->bwt_bind)->h_bwt = b->bwt;
+	return BMH_OK;
+}
+
+int bmh_sa_batch(bmh_ctx_t *ctx, const uint64_t *k, int64_t n, uint64_t *pos)
+{
+	if (!ctx || n < 0 || (n > 0 && (!k || !pos))) return BMH_E_ARG;
+	if (!ctx->bwt_bind) {
+		ctx->last_error = "no FM-index on the device (bmh_ctx_set_bwt)";
+		return BMH_E_ARG;
+	}
+	if (n == 0) return BMH_OK;
+	const DevBwt &B = ((bmh_bwt_binding *)ctx->bwt_bind)->dev;
+	for (int64_t i = 0; i < n; ++i)
+		if (k[i] > B.seq_len) {
+			ctx->last_error = "suffix-array index " + std::to_string(i) + " is beyond the index";
+			return BMH_E_ARG;
+		}
+	int rc;
+	BMH_HIP(ctx, hipSetDevice(ctx->device));
+	if ((rc = ensure(ctx, ctx->d_tasks, (size_t)n * 8)) || (rc = ensure(ctx, ctx->d_res, (size_t)n * 8))) return rc;
+	BMH_HIP(ctx, hipMemcpyAsync(ctx->d_tasks.p, k, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+	hipLaunchKernelGGL(sa_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 8192)), dim3(256), 0, ctx->stream, B,
+	                   (const uint64_t *)ctx->d_tasks.p, (long long)n, (uint64_t *)ctx->d_res.p);
+	BMH_HIP(ctx, hipGetLastError());
+	BMH_HIP(ctx, hipMemcpyAsync(pos, ctx->d_res.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+	BMH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	return BMH_OK;
+}
+
+int bmh_smem_batch(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const bmh_read_t *reads, uint32_t *call_off,
+                   bmh_smem_call_t *calls, size_t call_cap, uint64_t *intv_off, bmh_smem_intv_t *intv, size_t intv_cap)
+{
+	if (!ctx || !o || n_reads < 0 || (n_reads > 0 && (!reads || !call_off || !intv_off))) return BMH_E_ARG;
+	if (!ctx->bwt_bind) {
+		ctx->last_error = "no FM-index on the device (bmh_ctx_set_bwt)";
+		return BMH_E_ARG;
+	}
+	if (n_reads == 0) return BMH_OK;
+	const DevBwt &B = ((bmh_bwt_binding *)ctx->bwt_bind)->dev;
+	int rc, lmax = 1;
+	size_t bytes = 0;
+	std::vector<uint64_t> off((size_t)n_reads);
+	std::vector<int> len((size_t)n_reads);
+	for (int r = 0; r < n_reads; ++r) {
+		if (reads[r].l_seq < 0 || (reads[r].l_seq > 0 && !reads[r].seq)) return BMH_E_ARG;
+		off[(size_t)r] = bytes, len[(size_t)r] = reads[r].l_seq, bytes += (size_t)reads[r].l_seq;
+		lmax = std::max(lmax, reads[r].l_seq);
+	}
+	BMH_HIP(ctx, hipSetDevice(ctx->device));
+	ctx->pool_resident = false;
+	std::vector<uint8_t> pool(bytes + 16, 0);
+	for (int r = 0; r < n_reads; ++r)
+		if (reads[r].l_seq) memcpy(pool.data() + off[(size_t)r], reads[r].seq, (size_t)reads[r].l_seq);
+	const int grid = (int)std::min<long long>(((long long)n_reads + 63) / 64, 4096), lcap = lmax + 2;
+	// device outputs grow until everything fits (the totals are data dependent)
+	size_t d_calls = std::max<size_t>((size_t)n_reads * 8, 1024), d_intv = std::max<size_t>((size_t)n_reads * 32, 4096);
+	std::vector<bmh_smem_call_t> h_calls;
+	std::vector<uint32_t> h_read;
+	std::vector<Intv> h_intv;
+	unsigned long long totals[2] = {0, 0};
+	for (int attempt = 0; attempt < 6; ++attempt) {
+		const size_t hdr = 64, o_pool = hdr, o_off = o_pool + ((bytes + 16 + 63) & ~(size_t)63), o_len = o_off + (size_t)n_reads * 8,
+		             o_calls = (o_len + (size_t)n_reads * 4 + 63) & ~(size_t)63, o_cr = o_calls + d_calls * sizeof(bmh_smem_call_t),
+		             o_intv = (o_cr + d_calls * 4 + 63) & ~(size_t)63, total = o_intv + d_intv * sizeof(Intv);
+		if ((rc = ensure(ctx, ctx->d_scratch, total))) return rc;
+		if ((rc = ensure(ctx, ctx->d_sw, (size_t)grid * 3 * (size_t)lcap * 64 * sizeof(Intv)))) return rc;
+		uint8_t *d = (uint8_t *)ctx->d_scratch.p;
+		BMH_HIP(ctx, hipMemsetAsync(d, 0, hdr, ctx->stream));
+		BMH_HIP(ctx, hipMemcpyAsync(d + o_pool, pool.data(), bytes + 16, hipMemcpyHostToDevice, ctx->stream));
+		BMH_HIP(ctx, hipMemcpyAsync(d + o_off, off.data(), (size_t)n_reads * 8, hipMemcpyHostToDevice, ctx->stream));
+		BMH_HIP(ctx, hipMemcpyAsync(d + o_len, len.data(), (size_t)n_reads * 4, hipMemcpyHostToDevice, ctx->stream));
+		hipLaunchKernelGGL(smem_kernel, dim3((unsigned)grid), dim3(64), 0, ctx->stream, B, (const uint8_t *)(d + o_pool),
+		                   (const uint64_t *)(d + o_off), (const int *)(d + o_len), n_reads, *o, (Intv *)ctx->d_sw.p, lcap,
+		                   (bmh_smem_call_t *)(d + o_calls), (uint32_t *)(d + o_cr), (unsigned long long *)d,
+		                   (unsigned long long)d_calls, (Intv *)(d + o_intv), (unsigned long long)d_intv, (int *)(d + 16));
+		BMH_HIP(ctx, hipGetLastError());
+		BMH_HIP(ctx, hipMemcpyAsync(totals, d, 16, hipMemcpyDeviceToHost, ctx->stream));
+		BMH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		if (totals[0] <= d_calls && totals[1] <= d_intv) {
+			h_calls.resize((size_t)totals[0]), h_read.resize((size_t)totals[0]), h_intv.resize((size_t)totals[1]);
+			if (totals[0]) {
+				BMH_HIP(ctx, hipMemcpy(h_calls.data(), d + o_calls, (size_t)totals[0] * sizeof(bmh_smem_call_t), hipMemcpyDeviceToHost));
+				BMH_HIP(ctx, hipMemcpy(h_read.data(), d + o_cr, (size_t)totals[0] * 4, hipMemcpyDeviceToHost));
+			}
+			if (totals[1]) BMH_HIP(ctx, hipMemcpy(h_intv.data(), d + o_intv, (size_t)totals[1] * sizeof(Intv), hipMemcpyDeviceToHost));
+			break;
+		}
+		d_calls = std::max(d_calls, (size_t)totals[0] + 64), d_intv = std::max(d_intv, (size_t)totals[1] + 64);
+		if (attempt == 5) return BMH_E_NOMEM;
+	}
+	if (totals[0] > call_cap || totals[1] > intv_cap || (totals[0] && (!calls || (!intv && totals[1])))) {
+		ctx->last_error = "bmh_smem_batch: " + std::to_string(totals[0]) + " calls / " + std::to_string(totals[1]) +
+		                  " intervals do not fit the caller's arrays";
+		return BMH_E_CIGAR_CAP;
+	}
+	// the device appended in completion order; put every read's calls back in call order and its intervals behind one another
+	std::vector<uint32_t> cnt((size_t)n_reads + 1, 0);
+	for (size_t c = 0; c < h_calls.size(); ++c) ++cnt[(size_t)h_read[c] + 1];
+	for (int r = 0; r < n_reads; ++r) cnt[(size_t)r + 1] += cnt[(size_t)r];
+	for (int r = 0; r <= n_reads; ++r) call_off[r] = cnt[(size_t)r];
+	for (size_t c = 0; c < h_calls.size(); ++c) calls[cnt[h_read[c]] + h_calls[c].rsv] = h_calls[c]; // rsv = sequence number in the read
+	uint64_t used = 0;
+	for (int r = 0; r < n_reads; ++r) {
+		intv_off[r] = used;
+		uint64_t local = 0;
+		for (uint32_t c = call_off[r]; c < call_off[r + 1]; ++c) {
+			bmh_smem_call_t &cl = calls[c];
+			if (cl.n) memcpy(&intv[used + local], &h_intv[cl.first], (size_t)cl.n * sizeof(Intv));
+			cl.first = (uint32_t)local, cl.rsv = 0, local += (uint64_t)cl.n;
+		}
+		used += local;
+	}
+	intv_off[n_reads] = used;
+	return BMH_OK;
+}
+
+} // extern "C"

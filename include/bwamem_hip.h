@@ -322,6 +322,45 @@ int bmh_matesw_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n_pa
                      bmh_alnreg_v *regs, const bmh_pestat_t pes[4], const bmh_matesw_opt_t *o, bmh_dedup_fn dedup,
                      void *dedup_user, int *n_sw);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * FM-index queries of the seeding stage (first slice): super-maximal exact matches and suffix-
+ * array look-ups on the device, over the reference's own index arrays made resident in HBM.
+ * Replaces: bwt_smem1 (reference bwa-0.7.8/bwt.c:288-347; over bwt_extend :261-274 and bwt_2occ4 :191-219), called in the
+ *           order smem_next2 calls it for one read (bwamem.c:118-162 as driven by mem_insert_seed, bwamem.c:208-214), and
+ *           bwt_sa (bwt.c:85-95; over bwt_invPsi :52-58 and bwt_occ :107-129).
+ * Chaining (mem_insert_seed's B-tree, mem_chain_flt) stays host code; INTEGRATION.md shows how the reference's
+ * mem_chain consumes these results unchanged. */
+typedef struct bmh_bwt { /* the fields of bwt_t the queries read (bwt.h:45-57); arrays are borrowed, never modified */
+	uint64_t primary, L2[5], seq_len, bwt_size; /* bwt_size in 32-bit words */
+	const uint32_t *bwt;                        /* BWT with the interleaved occurrence counts (bwt.h:63-64 layout) */
+	int32_t sa_intv;
+	uint64_t n_sa;
+	const uint64_t *sa;
+} bmh_bwt_t;
+typedef struct bmh_smem_intv { uint64_t x[3], info; } bmh_smem_intv_t; /* == bwtintv_t, bwt.h:59-61 */
+typedef struct bmh_smem_opt {
+	int32_t min_seed_len; /* mem_opt_t.min_seed_len (only used to bound the look-ups, not the calls)            */
+	int32_t split_len;    /* (int)(min_seed_len*split_factor + .499), bwamem.c:211 (clamped to the read length there) */
+	int32_t split_width;  /* mem_opt_t.split_width                                                              */
+	int32_t start_width;  /* 2 with MEM_F_NO_EXACT, else 1, bwamem.c:212                                        */
+} bmh_smem_opt_t;
+typedef struct bmh_smem_call { /* one bwt_smem1 call and where its result intervals lie */
+	int32_t x, min_intv; /* arguments (bwt.c:288)                         */
+	int32_t ret, n;      /* return value and mem->n                       */
+	uint32_t first;      /* first interval in the read's slice of the pool */
+	uint32_t rsv;
+} bmh_smem_call_t;
+
+/* Make the index resident on the context's device (one copy per device and host array, shared by all contexts). */
+int bmh_ctx_set_bwt(bmh_ctx_t *ctx, const bmh_bwt_t *bwt);
+/* For every read: the bwt_smem1 calls of smem_next2's iteration, in order.  Read r's calls are
+ * calls[call_off[r] .. call_off[r+1]) and their intervals lie in intv[intv_off[r] + call.first ...].  call_off and
+ * intv_off have n_reads+1 entries.  BMH_E_CIGAR_CAP if a capacity is too small (nothing partial is returned). */
+int bmh_smem_batch(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const bmh_read_t *reads, uint32_t *call_off,
+                   bmh_smem_call_t *calls, size_t call_cap, uint64_t *intv_off, bmh_smem_intv_t *intv, size_t intv_cap);
+/* N x bwt_sa: pos[i] = position (doubled coordinate) of suffix-array entry k[i]. */
+int bmh_sa_batch(bmh_ctx_t *ctx, const uint64_t *k, int64_t n, uint64_t *pos);
+
 #ifdef __cplusplus
 }
 #endif

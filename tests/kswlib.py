@@ -527,3 +527,64 @@ def golden_matesw_groups():
         regs = split(g[key + "regs"], g[key + "regs_n"])
         exp = split(g[key + "exp"], g[key + "exp_n"])
         yield g[key + "params"], g[key + "opt"], g[key + "pes"], l_pac, pac, reads, regs, exp, g[key + "n_sw"].tolist()
+
+
+# ---- FM-index (seeding) ---------------------------------------------------------------------------------------------
+SMEM_INTV = np.dtype([("x0", "<u8"), ("x1", "<u8"), ("x2", "<u8"), ("info", "<u8")])
+SMEM_CALL = np.dtype([("x", "<i4"), ("min_intv", "<i4"), ("ret", "<i4"), ("n", "<i4"), ("first", "<u4"), ("rsv", "<u4")])
+SMEM_OPT = np.dtype([("min_seed_len", "<i4"), ("split_len", "<i4"), ("split_width", "<i4"), ("start_width", "<i4")])
+
+
+class CBwt(C.Structure):  # bmh_bwt_t
+    _fields_ = [("primary", C.c_uint64), ("L2", C.c_uint64 * 5), ("seq_len", C.c_uint64), ("bwt_size", C.c_uint64),
+                ("bwt", C.c_void_p), ("sa_intv", C.c_int32), ("n_sa", C.c_uint64), ("sa", C.c_void_p)]
+
+
+def make_cbwt(primary, L2, seq_len, bwt_words, sa_intv, sa, keep):
+    """bmh_bwt_t over numpy arrays (kept alive through `keep`)."""
+    bw = np.ascontiguousarray(bwt_words, dtype=np.uint32)
+    sa = np.ascontiguousarray(sa, dtype=np.uint64)
+    keep += [bw, sa]
+    b = CBwt()
+    b.primary, b.seq_len, b.bwt_size, b.sa_intv, b.n_sa = int(primary), int(seq_len), len(bw), int(sa_intv), len(sa)
+    for i in range(5):
+        b.L2[i] = int(L2[i])
+    b.bwt, b.sa = bw.ctypes.data, sa.ctypes.data
+    return b
+
+
+def orc_smem_calls(cb, opt, read):
+    """OUR restatement of the bwt_smem1 call sequence of one read -> (SMEM_CALL[], SMEM_INTV[])."""
+    lib = load_oracle()
+    read = np.ascontiguousarray(read, dtype=np.uint8)
+    L = len(read)
+    calls = np.zeros(2 * L + 4, dtype=SMEM_CALL)
+    pool = np.zeros(4 * (L + 2) * 4 + 64, dtype=SMEM_INTV)
+    used = C.c_int(0)
+    oo = np.ascontiguousarray(opt, dtype=SMEM_OPT)
+    lib.orc_smem_calls.restype = C.c_int
+    n = lib.orc_smem_calls(C.byref(cb), oo.ctypes.data_as(C.c_void_p), C.c_int(L), read.ctypes.data_as(C.c_void_p),
+                           calls.ctypes.data_as(C.c_void_p), C.c_int(len(calls)), pool.ctypes.data_as(C.c_void_p),
+                           C.c_int(len(pool)), C.byref(used))
+    assert n >= 0
+    return calls[:n].copy(), pool[:used.value].copy()
+
+
+def orc_sa(cb, ks):
+    lib = load_oracle()
+    lib.orc_bwt_sa.restype = C.c_uint64
+    return np.array([lib.orc_bwt_sa(C.byref(cb), C.c_uint64(int(k))) for k in ks], dtype=np.uint64)
+
+
+def golden_fmindex():
+    """(bmh_bwt_t over the fixture's index, raw arrays, opt, reads, per-read (calls, intervals), sa_k, sa_pos)."""
+    g = load_golden("fmindex_golden.npz")
+    keep = []
+    cb = make_cbwt(int(g["primary"]), g["L2"], int(g["seq_len"]), g["bwt"], int(g["sa_intv"]), g["sa"], keep)
+    raw = (int(g["primary"]), [int(x) for x in g["L2"]], int(g["seq_len"]), g["bwt"], int(g["sa_intv"]), g["sa"])
+    reads, per, o, c0, i0 = [], [], 0, 0, 0
+    for L, cn, inn in zip(g["read_len"], g["call_n"], g["intv_n"]):
+        reads.append(g["reads"][o:o + L].copy())
+        per.append((g["calls"][c0:c0 + cn].copy(), g["intv"][i0:i0 + inn].copy()))
+        o, c0, i0 = o + L, c0 + cn, i0 + inn
+    return cb, keep, raw, g["opt"], reads, per, g["sa_k"], g["sa_pos"]

@@ -236,3 +236,81 @@ def ref_matesw_pairs(idx, opt, pes, reads, regs):
                                   len(mate), mate.ctypes.data_as(C.c_void_p), C.byref(c_regs, (2 * k + 1 - i) * C.sizeof(kswlib.CAlnregV)))
         ns.append(n)
     return kswlib.regs_from_c(c_regs), ns
+
+
+# ---- FM-index: the reference's own bwt_t and query functions (bwt.h:45-57, bwt.c) -----------------------------------
+class BwtT(C.Structure):
+    _fields_ = [("primary", C.c_uint64), ("L2", C.c_uint64 * 5), ("seq_len", C.c_uint64), ("bwt_size", C.c_uint64),
+                ("bwt", C.POINTER(C.c_uint32)), ("cnt_table", C.c_uint32 * 256), ("sa_intv", C.c_int), ("n_sa", C.c_uint64),
+                ("sa", C.POINTER(C.c_uint64))]
+
+
+class BwtIntvV(C.Structure):  # bwtintv_v, bwt.h:63
+    _fields_ = [("n", C.c_size_t), ("m", C.c_size_t), ("a", C.c_void_p)]
+
+
+def bwt_arrays(idx):
+    """(primary, L2[5], seq_len, bwt words, sa_intv, sa) copied out of the loaded index."""
+    b = C.cast(idx.contents.bwt, C.POINTER(BwtT)).contents
+    words = np.ctypeslib.as_array(b.bwt, shape=(b.bwt_size,)).copy()
+    sa = np.ctypeslib.as_array(b.sa, shape=(b.n_sa,)).copy()
+    return int(b.primary), [int(x) for x in b.L2], int(b.seq_len), words, int(b.sa_intv), sa
+
+
+def ref_smem1(idx, read, x, min_intv):
+    """The reference's bwt_smem1 (bwt.c:288) -> (ret, SMEM_INTV[])."""
+    L = lib()
+    L.bwt_smem1.restype = C.c_int
+    L.bwt_smem1.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    read = np.ascontiguousarray(read, dtype=np.uint8)
+    mem = BwtIntvV(0, 0, None)
+    ret = L.bwt_smem1(idx.contents.bwt, len(read), read.ctypes.data_as(C.c_void_p), x, min_intv, C.byref(mem), None)
+    out = np.zeros(mem.n, dtype=kswlib.SMEM_INTV)
+    if mem.n:
+        C.memmove(out.ctypes.data, mem.a, mem.n * 32)
+    if mem.a:
+        _libc.free(mem.a)
+    return ret, out
+
+
+def ref_smem_iter(idx, opt, read):
+    """smem_next2 (bwamem.c:118) iterated as mem_insert_seed does (bwamem.c:208-214): list of (start after the
+    iteration, merged SMEM_INTV[])."""
+    L = lib()
+    L.smem_itr_init.restype = C.c_void_p
+    L.smem_itr_init.argtypes = [C.c_void_p]
+    L.smem_set_query.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.smem_next2.restype = C.POINTER(BwtIntvV)
+    L.smem_next2.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.smem_itr_destroy.argtypes = [C.c_void_p]
+    read = np.ascontiguousarray(read, dtype=np.uint8)
+    o = opt.contents
+    split_len = min(int(o.min_seed_len * o.split_factor + .499), len(read))
+    itr = L.smem_itr_init(idx.contents.bwt)
+    L.smem_set_query(itr, len(read), read.ctypes.data_as(C.c_void_p))
+    out = []
+    while True:
+        a = L.smem_next2(itr, split_len, o.split_width, 2 if o.flag & 0x40 else 1)
+        if not a:
+            break
+        v = np.zeros(a.contents.n, dtype=kswlib.SMEM_INTV)
+        if a.contents.n:
+            C.memmove(v.ctypes.data, a.contents.a, a.contents.n * 32)
+        out.append(v)
+    L.smem_itr_destroy(itr)
+    return out
+
+
+def ref_sa(idx, ks):
+    L = lib()
+    L.bwt_sa.restype = C.c_uint64
+    L.bwt_sa.argtypes = [C.c_void_p, C.c_uint64]
+    return np.array([L.bwt_sa(idx.contents.bwt, int(k)) for k in ks], dtype=np.uint64)
+
+
+def smem_opt_of(opt, read_len=None):
+    o = opt.contents
+    so = np.zeros((), dtype=kswlib.SMEM_OPT)
+    so["min_seed_len"], so["split_len"] = o.min_seed_len, int(o.min_seed_len * o.split_factor + .499)
+    so["split_width"], so["start_width"] = o.split_width, 2 if o.flag & 0x40 else 1
+    return so

