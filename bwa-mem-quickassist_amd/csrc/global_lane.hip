@@ -18,6 +18,8 @@
 // Direction bytes (same encoding as ksw.c:547-561) are packed four per dword and written to a per-wave HBM slab
 // laid out [row][slot/4][lane], so both the stores of the fill and the loads of the per-lane traceback coalesce.
 // The traceback (ksw.c:566-581) is the reference's loop, one path per lane, CIGAR words written by the lane itself.
+#include <algorithm>
+
 #include "bmh_ctx.h"
 #include "bmh_device.h"
 
@@ -236,7 +238,10 @@ int launch_global_lane(bmh_ctx *ctx, int c, const uint8_t *d_pool, const bmh_glb
 	const long long resident = (long long)ncu * 4 * (c <= 64 ? BMH_GL_WAVES64 : BMH_GL_WAVES128) * 2; // persistent: ~2x the resident waves
 	if (grid > resident) grid = resident;
 	// one slab serves both lane kernels of a launch (they run back to back on the stream): size it for the larger one
-	const size_t slab = (size_t)ncu * 4 * 2 * 2 * (size_t)rows_cap * (size_t)(128 / 4) * 64 * 4;
+	// (and for the waves this launch can actually have in flight: a context that only ever sees small batches must not
+	// pin gigabytes)
+	const size_t slab_waves = (size_t)std::min<long long>((n + 63) / 64, (long long)ncu * 4 * 2 * 2);
+	const size_t slab = slab_waves * (size_t)rows_cap * (size_t)(128 / 4) * 64 * 4;
 	int rc = ensure(ctx, ctx->d_zslab, slab);
 	if (rc) return rc;
 #define BMH_LAUNCH_GL(CC)                                                                                             \

@@ -19,8 +19,28 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <pthread.h>
+#include <semaphore.h>
+
 #include "../../include/bwamem_hip.h"
 #include "tls_ctx.h"
+
+/* At most this many host threads are inside a GPU batch call at a time ($BMH_GPU_CONCURRENCY, default 8): the calls of
+ * more threads than that only queue up behind one another on the device, and their workspace (re)allocations, which
+ * synchronise the whole device, collide.  The host work around the calls (chaining, folding) is not limited. */
+static sem_t g_gpu_sem;
+static pthread_once_t g_gpu_once = PTHREAD_ONCE_INIT;
+static void gpu_sem_init(void)
+{
+	const char *e = getenv("BMH_GPU_CONCURRENCY");
+	sem_init(&g_gpu_sem, 0, e && atoi(e) > 0 ? (unsigned)atoi(e) : 8u);
+}
+static void gpu_enter(void)
+{
+	pthread_once(&g_gpu_once, gpu_sem_init);
+	while (sem_wait(&g_gpu_sem) != 0) {}
+}
+static void gpu_leave(void) { sem_post(&g_gpu_sem); }
 
 typedef struct { /* mem_opt_t of the fork, bwamem.h:21-48 */
 	int a, b, o_del, e_del, o_ins, e_ins, pen_unpaired, pen_clip5, pen_clip3, w, zdrop;
@@ -59,6 +79,153 @@ static int pre_short(void *user, int r, int ci, bmh_alnreg_v *av) /* bwamem.c:11
 	return mem_chain2aln_short(u->opt, u->l_pac, u->pac, u->reads[r].l_seq, u->reads[r].seq, &u->chains[r].a[ci], av);
 }
 
+/* ---- seeding: the batch's FM-index queries on the GPU, the reference's own mem_chain on top -----------------------
+ * mem_chain (bwamem.c:283) = SMEM search (smem_next2 -> bwt_smem1) + suffix-array look-ups (bwt_sa) + chaining in a
+ * B-tree.  The first two are pure functions of (index, read); the shim computes them for the whole batch up front
+ * (bmh_smem_batch, bmh_sa_batch) and serves them to the untouched mem_chain through interposed bwt_smem1 / bwt_sa
+ * (bwt.h).  A call that is not in the batch's tables goes to the reference's own function.  BMH_SEED_BATCH=0 disables. */
+typedef struct { /* bwt_t, bwt.h:45-57 */
+	uint64_t primary, L2[5], seq_len, bwt_size;
+	uint32_t *bwt;
+	uint32_t cnt_table[256];
+	int sa_intv;
+	uint64_t n_sa;
+	uint64_t *sa;
+} ref_bwt_t;
+typedef struct { size_t n, m; bmh_smem_intv_t *a; } ref_bwtintv_v; /* bwt.h:63 */
+
+typedef struct {
+	const ref_bwt_t *bwt;
+	int n_reads;
+	const bmh_read_t *reads;
+	uint32_t *call_off;
+	bmh_smem_call_t *calls;
+	uint64_t *intv_off;
+	bmh_smem_intv_t *intv;
+	uint64_t *sa_k, *sa_pos; /* sorted keys and their positions */
+	size_t n_sa;
+	long long smem_hit, smem_miss, sa_hit, sa_miss;
+} qa_seed_t;
+static __thread qa_seed_t *qa_seed; /* the batch this thread is chaining, or NULL */
+static __thread int qa_seed_cur;    /* index of the read mem_chain is working on */
+
+static int cmp_u64(const void *a, const void *b)
+{
+	const uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+	return x < y ? -1 : x > y;
+}
+
+static void qa_seed_batch_begin(bmh_ctx_t *ctx, const ref_mem_opt_t *opt, const ref_bwt_t *bwt, int n, const bmh_read_t *reads)
+{
+	const char *e = getenv("BMH_SEED_BATCH");
+	bmh_bwt_t ib;
+	bmh_smem_opt_t so;
+	qa_seed_t *S;
+	size_t tot = 0, call_cap, intv_cap, nk = 0, k;
+	int r, rc, i;
+	qa_seed = 0;
+	if (e && e[0] == '0') return;
+	ib.primary = bwt->primary, ib.seq_len = bwt->seq_len, ib.bwt_size = bwt->bwt_size, ib.bwt = bwt->bwt;
+	for (i = 0; i < 5; ++i) ib.L2[i] = bwt->L2[i];
+	ib.sa_intv = bwt->sa_intv, ib.n_sa = bwt->n_sa, ib.sa = bwt->sa;
+	if ((rc = bmh_ctx_set_bwt(ctx, &ib))) bmh_tls_die(bmh_last_error(ctx), rc);
+	so.min_seed_len = opt->min_seed_len, so.split_len = (int)(opt->min_seed_len * opt->split_factor + .499); /* bwamem.c:211 */
+	so.split_width = opt->split_width, so.start_width = (opt->flag & REF_MEM_F_NO_EXACT) ? 2 : 1;           /* bwamem.c:212 */
+	for (r = 0; r < n; ++r) tot += (size_t)reads[r].l_seq;
+	S = (qa_seed_t *)calloc(1, sizeof(*S));
+	S->bwt = bwt, S->n_reads = n, S->reads = reads;
+	S->call_off = (uint32_t *)malloc(4 * ((size_t)n + 1)), S->intv_off = (uint64_t *)malloc(8 * ((size_t)n + 1));
+	for (call_cap = 2 * tot / 8 + 64 * (size_t)n + 64, intv_cap = 8 * tot + 1024;; call_cap *= 2, intv_cap *= 2) {
+		S->calls = (bmh_smem_call_t *)malloc(sizeof(bmh_smem_call_t) * call_cap);
+		S->intv = (bmh_smem_intv_t *)malloc(sizeof(bmh_smem_intv_t) * intv_cap);
+		rc = bmh_smem_batch(ctx, &so, n, reads, S->call_off, S->calls, call_cap, S->intv_off, S->intv, intv_cap);
+		if (rc != BMH_E_CIGAR_CAP) break;
+		free(S->calls), free(S->intv);
+	}
+	if (rc) bmh_tls_die(bmh_last_error(ctx), rc);
+	/* the suffix-array entries mem_insert_seed will ask for (bwamem.c:218-225): every occurrence of every interval that
+	 * is long and rare enough -- taken over ALL returned intervals, a superset of the merged list it walks */
+	for (k = 0; k < S->intv_off[n]; ++k) {
+		const bmh_smem_intv_t *p = &S->intv[k];
+		const int slen = (int)((uint32_t)p->info - (uint32_t)(p->info >> 32));
+		if (slen >= opt->min_seed_len && p->x[2] <= (uint64_t)opt->max_occ) nk += (size_t)p->x[2];
+	}
+	S->sa_k = (uint64_t *)malloc(8 * (nk + 1)), S->sa_pos = (uint64_t *)malloc(8 * (nk + 1));
+	for (k = 0, nk = 0; k < S->intv_off[n]; ++k) {
+		const bmh_smem_intv_t *p = &S->intv[k];
+		const int slen = (int)((uint32_t)p->info - (uint32_t)(p->info >> 32));
+		uint64_t j;
+		if (slen >= opt->min_seed_len && p->x[2] <= (uint64_t)opt->max_occ)
+			for (j = 0; j < p->x[2]; ++j) S->sa_k[nk++] = p->x[0] + j;
+	}
+	qsort(S->sa_k, nk, 8, cmp_u64);
+	for (k = 0, S->n_sa = 0; k < nk; ++k) /* unique */
+		if (S->n_sa == 0 || S->sa_k[S->n_sa - 1] != S->sa_k[k]) S->sa_k[S->n_sa++] = S->sa_k[k];
+	if ((rc = bmh_sa_batch(ctx, S->sa_k, (int64_t)S->n_sa, S->sa_pos))) bmh_tls_die(bmh_last_error(ctx), rc);
+	qa_seed = S;
+}
+
+static long long g_seed_stats[4];
+static void qa_seed_batch_end(void)
+{
+	qa_seed_t *S = qa_seed;
+	qa_seed = 0;
+	if (!S) return;
+	__sync_fetch_and_add(&g_seed_stats[0], S->smem_hit), __sync_fetch_and_add(&g_seed_stats[1], S->smem_miss);
+	__sync_fetch_and_add(&g_seed_stats[2], S->sa_hit), __sync_fetch_and_add(&g_seed_stats[3], S->sa_miss);
+	free(S->call_off), free(S->calls), free(S->intv_off), free(S->intv), free(S->sa_k), free(S->sa_pos), free(S);
+}
+
+typedef int (*smem1_fn)(const void *, int, const uint8_t *, int, int, ref_bwtintv_v *, ref_bwtintv_v **);
+int bwt_smem1(const void *bwt, int len, const uint8_t *q, int x, int min_intv, ref_bwtintv_v *mem, ref_bwtintv_v *tmpvec[2])
+{
+	static smem1_fn next;
+	qa_seed_t *S = qa_seed;
+	if (S && (const void *)S->bwt == bwt && qa_seed_cur < S->n_reads && S->reads[qa_seed_cur].seq == q && S->reads[qa_seed_cur].l_seq == len) {
+		uint32_t c;
+		for (c = S->call_off[qa_seed_cur]; c < S->call_off[qa_seed_cur + 1]; ++c) {
+			const bmh_smem_call_t *cl = &S->calls[c];
+			if (cl->x == x && cl->min_intv == min_intv) {
+				if (mem->m < (size_t)cl->n) { /* kv_resize */
+					mem->m = (size_t)cl->n;
+					mem->a = (bmh_smem_intv_t *)realloc(mem->a, sizeof(bmh_smem_intv_t) * mem->m);
+				}
+				mem->n = (size_t)cl->n;
+				if (cl->n) memcpy(mem->a, &S->intv[S->intv_off[qa_seed_cur] + cl->first], sizeof(bmh_smem_intv_t) * (size_t)cl->n);
+				++S->smem_hit;
+				return cl->ret;
+			}
+		}
+		++S->smem_miss;
+	}
+	if (!next) next = (smem1_fn)dlsym(RTLD_NEXT, "bwt_smem1");
+	if (!next) bmh_tls_die("no other bwt_smem1 is loaded", BMH_E_ARG);
+	return next(bwt, len, q, x, min_intv, mem, tmpvec);
+}
+
+typedef uint64_t (*sa_fn)(const void *, uint64_t);
+uint64_t bwt_sa(const void *bwt, uint64_t k)
+{
+	static sa_fn next;
+	qa_seed_t *S = qa_seed;
+	if (S && (const void *)S->bwt == bwt) {
+		size_t lo = 0, hi = S->n_sa;
+		while (lo < hi) {
+			const size_t mid = (lo + hi) >> 1;
+			if (S->sa_k[mid] < k) lo = mid + 1;
+			else hi = mid;
+		}
+		if (lo < S->n_sa && S->sa_k[lo] == k) {
+			++S->sa_hit;
+			return S->sa_pos[lo];
+		}
+		++S->sa_miss;
+	}
+	if (!next) next = (sa_fn)dlsym(RTLD_NEXT, "bwt_sa");
+	if (!next) bmh_tls_die("no other bwt_sa is loaded", BMH_E_ARG);
+	return next(bwt, k);
+}
+
 bmh_alnreg_v *mem_align1_core_batched(const ref_mem_opt_t *opt, const void *bwt, const ref_bntseq_head_t *bns,
                                       const uint8_t *pac, ref_bseq1_t *seqs, int start, int batch_size)
 {
@@ -70,28 +237,38 @@ bmh_alnreg_v *mem_align1_core_batched(const ref_mem_opt_t *opt, const void *bwt,
 	pre_ud_t ud;
 	int b, i, rc;
 
-	for (b = 0; b < batch_size; ++b) { /* CPU stages before the path, unchanged: bwamem.c:1093-1097 */
+	for (b = 0; b < batch_size; ++b) { /* bwamem.c:1093-1094 */
 		ref_bseq1_t *s = &seqs[start + b];
 		for (i = 0; i < s->l_seq; ++i) s->seq[i] = s->seq[i] < 4 ? s->seq[i] : (char)nst_nt4_table[(int)s->seq[i]];
-		chn[b] = mem_chain(opt, bwt, bns->l_pac, s->l_seq, (uint8_t *)s->seq);
-		chn[b].n = (size_t)mem_chain_flt(opt, (int)chn[b].n, chn[b].a);
 		reads[b].l_seq = s->l_seq, reads[b].seq = (const uint8_t *)s->seq;
 	}
-
 	memset(&p, 0, sizeof(p)); /* the hot-path fields of mem_opt_t */
 	p.o_del = opt->o_del, p.e_del = opt->e_del, p.o_ins = opt->o_ins, p.e_ins = opt->e_ins, p.zdrop = opt->zdrop;
 	p.a = opt->a, p.w = opt->w, p.pen_clip5 = opt->pen_clip5, p.pen_clip3 = opt->pen_clip3;
 	memcpy(p.mat, opt->mat, 25);
+	gpu_enter(); /* contexts are taken inside the limited section, so no more of them exist than can be busy */
 	ctx = bmh_pool_get(&p);
-	{ /* reference resident in HBM, shared by all threads: the kernels do bns_get_seq themselves.  BMH_PAC_RESIDENT=0
+	qa_seed_batch_begin(ctx, opt, (const ref_bwt_t *)bwt, batch_size, reads); /* SMEMs + suffix-array look-ups of the batch on the GPU */
+	bmh_pool_put(ctx);
+	gpu_leave();
+	for (b = 0; b < batch_size; ++b) { /* chaining stays the reference's own code: bwamem.c:1095-1097 */
+		qa_seed_cur = b;
+		chn[b] = mem_chain(opt, bwt, bns->l_pac, reads[b].l_seq, reads[b].seq);
+		chn[b].n = (size_t)mem_chain_flt(opt, (int)chn[b].n, chn[b].a);
+	}
+	qa_seed_batch_end();
+	ud.opt = opt, ud.l_pac = bns->l_pac, ud.pac = pac, ud.reads = reads, ud.chains = chn;
+	gpu_enter();
+	ctx = bmh_pool_get(&p);
+	{ /* reference resident in HBM, shared by all contexts: the kernels do bns_get_seq themselves.  BMH_PAC_RESIDENT=0
 	   * falls back to host-decoded windows in the pool. */
 		const char *e = getenv("BMH_PAC_RESIDENT");
 		if (!(e && e[0] == '0') && (rc = bmh_ctx_set_pac(ctx, pac, bns->l_pac))) bmh_tls_die(bmh_last_error(ctx), rc);
 	}
-	ud.opt = opt, ud.l_pac = bns->l_pac, ud.pac = pac, ud.reads = reads, ud.chains = chn;
 	if ((rc = bmh_chain2aln_batch(ctx, bns->l_pac, pac, batch_size, reads, chn, pre_short, &ud, regs))) /* bwamem.c:1110 */
 		bmh_tls_die(bmh_last_error(ctx), rc);
 	bmh_pool_put(ctx);
+	gpu_leave();
 
 	for (b = 0; b < batch_size; ++b) { /* CPU stages after the path, unchanged: bwamem.c:1106,1112-1117 */
 		for (i = 0; i < (int)chn[b].n; ++i) free(chn[b].a[i].seeds);
@@ -292,10 +469,13 @@ static void qa_cigar_slice(void *data, int k, int tid)
 	S->res = (bmh_cigar_res_t *)malloc(sizeof(*S->res) * n_req);
 	S->cig = (uint32_t *)malloc(4 * cw), S->md = (char *)malloc(mb);
 	{
-		bmh_ctx_t *ctx = qa_slice_ctx(J);
+		bmh_ctx_t *ctx;
+		gpu_enter();
+		ctx = qa_slice_ctx(J);
 		if ((rc = bmh_reg2cigar_batch(ctx, J->bns->l_pac, J->pac, J->reads, (int64_t)n_req, S->reqs, S->res, S->cig, cw, S->md, mb)))
 			bmh_tls_die(bmh_last_error(ctx), rc);
 		bmh_pool_put(ctx);
+		gpu_leave();
 	}
 }
 
@@ -349,6 +529,7 @@ static void qa_matesw_slice(void *data, int k, int tid)
 	int rc;
 	(void)tid;
 	if (hi <= lo) return;
+	gpu_enter();
 	ctx = qa_slice_ctx(J);
 	mo.pen_unpaired = J->opt->pen_unpaired, mo.max_matesw = J->opt->max_matesw, mo.min_seed_len = J->opt->min_seed_len, mo.rsv = 0;
 	if ((rc = bmh_matesw_batch(ctx, J->bns->l_pac, J->pac, hi - lo, J->reads + 2 * lo, J->regs + 2 * lo, J->pes, &mo, qa_dedup,
@@ -356,6 +537,7 @@ static void qa_matesw_slice(void *data, int k, int tid)
 		bmh_tls_die(bmh_last_error(ctx), rc);
 	bmh_driver_stats(ctx, &st);
 	bmh_pool_put(ctx);
+	gpu_leave();
 	__sync_fetch_and_add(&g_msw_calls, st.ext_tasks), __sync_fetch_and_add(&g_msw_bytes, st.pool_bytes);
 	if (st.rounds > g_msw_rounds_max) g_msw_rounds_max = st.rounds; /* (a benign race: statistics only) */
 }
@@ -434,6 +616,9 @@ void mem_process_seqs(const ref_mem_opt_t *opt, const void *bwt, const ref_bntse
 	if (pe) kt_for(opt->n_threads, qa_worker2_pe, &w, n >> 1); /* bwamem.c:1319 */
 	else kt_for(opt->n_threads, qa_worker2_se, &w, n);
 	t_[4] = realtime();
+	if (getenv("BMH_VERBOSE"))
+		fprintf(stderr, "[bwamem_hip] seeding: bwt_smem1 %lld from the batch / %lld on the host, bwt_sa %lld / %lld\n", g_seed_stats[0],
+		        g_seed_stats[1], g_seed_stats[2], g_seed_stats[3]);
 	if (getenv("BMH_VERBOSE"))
 		fprintf(stderr, "[bwamem_hip] chunk of %d reads: phase 1 %.3f s, pestat + mate rescue %.3f s, CIGAR batch %.3f s, phase 2 %.3f s\n", n,
 		        t_[1] - t_[0], t_[2] - t_[1], t_[3] - t_[2], t_[4] - t_[3]);

@@ -3,7 +3,8 @@ pipeline_ref.sh: SAM of the fork == SAM of stock).
 
 REF = the reference compiled by oracle/Makefile (oracle/_ref/bwa), untouched.
 DUT = the same binary with libbwamem_hip_dropin.so LD_PRELOADed: phase 1 goes through the fork's
-      batching seam mem_align1_core_batched -> bmh_chain2aln_batch (GPU extension kernels, one
+      batching seam mem_align1_core_batched -> FM-index queries of the batch on the GPU (bmh_smem_batch, bmh_sa_batch,
+      served to the reference's own mem_chain) -> bmh_chain2aln_batch (GPU extension kernels, one
       context per host thread); for pairs, mem_process_seqs itself is taken over so that the whole chunk's mate
       rescue (mem_matesw, ksw_align2) runs as bmh_matesw_batch; every ksw_global2 of phase 2 and the ksw_align2 of
       short chains are per-call GPU drop-ins.
@@ -96,6 +97,9 @@ def test_se_sam_identical(genome, extra):
     import re
     m = re.findall(r"bwa_gen_cigar2 served (\d+) calls from the batch, (\d+) went to the host", _run.last_stderr)
     assert m and sum(int(x[0]) for x in m) >= len(reads) // 2 and sum(int(x[1]) for x in m) == 0
+    # ... and phase 1's FM-index queries (bwt_smem1, bwt_sa) from the batch's GPU results, none computed on the host
+    m = re.findall(r"seeding: bwt_smem1 (\d+) from the batch / (\d+) on the host, bwt_sa (\d+) / (\d+)", _run.last_stderr)
+    assert m and int(m[-1][0]) > len(reads) and int(m[-1][1]) == 0 and int(m[-1][2]) > len(reads) // 2 and int(m[-1][3]) == 0
 
 
 def test_pe_sam_identical(genome):
