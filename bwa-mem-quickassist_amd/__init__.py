@@ -263,13 +263,18 @@ class Context:
             keep.append(r)
             c_reads[k].l_seq, c_reads[k].seq = len(r), r.ctypes.data
             tot += len(r)
-        call_cap, intv_cap = 2 * tot + 16, 64 * tot + 1024
+        call_cap, intv_cap = tot // 4 + 64 * n + 64, 2 * tot + 1024
         call_off = np.zeros(n + 1, dtype=np.uint32)
         intv_off = np.zeros(n + 1, dtype=np.uint64)
-        calls = np.zeros(call_cap, dtype=SMEM_CALL)
-        intv = np.zeros(intv_cap, dtype=SMEM_INTV)
-        self._check(lib().bmh_smem_batch(self._h, _ptr(opt), n, C.cast(c_reads, C.c_void_p), _ptr(call_off), _ptr(calls),
-                                         C.c_size_t(call_cap), _ptr(intv_off), _ptr(intv), C.c_size_t(intv_cap)))
+        while True:
+            calls = np.zeros(call_cap, dtype=SMEM_CALL)
+            intv = np.zeros(intv_cap, dtype=SMEM_INTV)
+            rc = lib().bmh_smem_batch(self._h, _ptr(opt), n, C.cast(c_reads, C.c_void_p), _ptr(call_off), _ptr(calls),
+                                      C.c_size_t(call_cap), _ptr(intv_off), _ptr(intv), C.c_size_t(intv_cap))
+            if rc != BMH_E_CIGAR_CAP:
+                break
+            call_cap, intv_cap = 2 * call_cap, 4 * intv_cap  # totals are data dependent: grow and ask again
+        self._check(rc)
         out = []
         for r in range(n):
             out.append((calls[call_off[r]:call_off[r + 1]].copy(), intv[int(intv_off[r]):int(intv_off[r + 1])].copy()))

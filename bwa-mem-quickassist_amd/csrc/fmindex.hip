@@ -309,9 +309,14 @@ int bmh_sa_batch(bmh_ctx_t *ctx, const uint64_t *k, int64_t n, uint64_t *pos)
 	BMH_HIP(ctx, hipSetDevice(ctx->device));
 	if ((rc = ensure(ctx, ctx->d_tasks, (size_t)n * 8)) || (rc = ensure(ctx, ctx->d_res, (size_t)n * 8))) return rc;
 	BMH_HIP(ctx, hipMemcpyAsync(ctx->d_tasks.p, k, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+	if (ctx->timing) BMH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
 	hipLaunchKernelGGL(sa_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 8192)), dim3(256), 0, ctx->stream, B,
 	                   (const uint64_t *)ctx->d_tasks.p, (long long)n, (uint64_t *)ctx->d_res.p);
 	BMH_HIP(ctx, hipGetLastError());
+	if (ctx->timing) {
+		BMH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+		ctx->ev_valid = true;
+	}
 	BMH_HIP(ctx, hipMemcpyAsync(pos, ctx->d_res.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
 	BMH_HIP(ctx, hipStreamSynchronize(ctx->stream));
 	return BMH_OK;
@@ -359,11 +364,16 @@ int bmh_smem_batch(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const b
 		BMH_HIP(ctx, hipMemcpyAsync(d + o_pool, pool.data(), bytes + 16, hipMemcpyHostToDevice, ctx->stream));
 		BMH_HIP(ctx, hipMemcpyAsync(d + o_off, off.data(), (size_t)n_reads * 8, hipMemcpyHostToDevice, ctx->stream));
 		BMH_HIP(ctx, hipMemcpyAsync(d + o_len, len.data(), (size_t)n_reads * 4, hipMemcpyHostToDevice, ctx->stream));
+		if (ctx->timing) BMH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
 		hipLaunchKernelGGL(smem_kernel, dim3((unsigned)grid), dim3(64), 0, ctx->stream, B, (const uint8_t *)(d + o_pool),
 		                   (const uint64_t *)(d + o_off), (const int *)(d + o_len), n_reads, *o, (Intv *)ctx->d_sw.p, lcap,
 		                   (bmh_smem_call_t *)(d + o_calls), (uint32_t *)(d + o_cr), (unsigned long long *)d,
 		                   (unsigned long long)d_calls, (Intv *)(d + o_intv), (unsigned long long)d_intv, (int *)(d + 16));
 		BMH_HIP(ctx, hipGetLastError());
+		if (ctx->timing) {
+			BMH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+			ctx->ev_valid = true;
+		}
 		BMH_HIP(ctx, hipMemcpyAsync(totals, d, 16, hipMemcpyDeviceToHost, ctx->stream));
 		BMH_HIP(ctx, hipStreamSynchronize(ctx->stream));
 		if (totals[0] <= d_calls && totals[1] <= d_intv) {

@@ -34,10 +34,19 @@ void orc_bwt_occ4(const bmh_bwt_t *b, uint64_t k, uint64_t cnt[4]) /* bwt.c:159-
 	}
 }
 
+static uint64_t g_extends; /* statistics for the bench (not thread-safe; single-threaded use only) */
+uint64_t orc_fm_extends(int reset)
+{
+	const uint64_t v = g_extends;
+	if (reset) g_extends = 0;
+	return v;
+}
+
 void orc_bwt_extend(const bmh_bwt_t *b, const bmh_smem_intv_t *ik, bmh_smem_intv_t ok[4], int is_back) /* bwt.c:261-274 */
 {
 	uint64_t tk[4], tl[4];
 	int i;
+	++g_extends;
 	orc_bwt_occ4(b, ik->x[!is_back] - 1, tk);
 	orc_bwt_occ4(b, ik->x[!is_back] - 1 + ik->x[2], tl);
 	for (i = 0; i < 4; ++i) {

@@ -26,6 +26,7 @@ void orc_bwt_extend(const bmh_bwt_t *b, const bmh_smem_intv_t *ik, bmh_smem_intv
 /* mem must have room for len+1 intervals; returns the next start (bwt.c:319) and *n_mem */
 int orc_bwt_smem1(const bmh_bwt_t *b, int len, const uint8_t *q, int x, int min_intv, bmh_smem_intv_t *mem, int *n_mem);
 uint64_t orc_bwt_sa(const bmh_bwt_t *b, uint64_t k);
+uint64_t orc_fm_extends(int reset); /* number of orc_bwt_extend calls so far (bench statistics; not thread-safe) */
 /* call log of one read: calls[c] = {x, min_intv, ret, n, first} with intervals in pool[first .. first+n).
  * Returns the number of calls, or -1 if a capacity is too small. */
 int orc_smem_calls(const bmh_bwt_t *b, const bmh_smem_opt_t *o, int len, const uint8_t *q, bmh_smem_call_t *calls,
