@@ -34,6 +34,8 @@ def main():
     ap.add_argument("--workload", default="150bp", choices=["150bp", "mixed100-300"])
     ap.add_argument("--sw-tasks", type=int, default=400_000,
                     help="mate-rescue Smith-Waterman tasks for the secondary measurement (0 = skip)")
+    ap.add_argument("--seed-reads", type=int, default=200_000,
+                    help="reads for the secondary FM-index (seeding) measurement; needs oracle/_ref to build an index (0 = skip)")
     ap.add_argument("--target-source", default="pool", choices=["pool", "pac"],
                     help="pac: targets decoded on the fly from a 2-bit reference resident in HBM (BMH_F_TPAC)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (rank 0, N=1 only)")
@@ -216,6 +218,84 @@ def main():
                         "cpu_reference_equal": same, "cpu_sample": "%d tasks, reference ksw_align2 (SSE2) on %d threads" % (nr, ncores)})
         del ds_pool, ds_tasks, ds_res
 
+    # ---- secondary measurement: FM-index queries of the seeding stage, N=1 only.  The index is
+    # built by the compiled reference (oracle/_ref/bwa index) over a synthetic genome; skipped where oracle/_ref is absent.
+    seedb = None
+    if world == 1 and args.seed_reads > 0:
+        import reflib
+        if reflib.have_ref_bwa() and os.path.exists(os.path.join(kswlib.REF_DIR, "libref_seed_shim.so")):
+            import ctypes as C
+            import tempfile
+            rng = np.random.default_rng(20261010)
+            tmpd = tempfile.mkdtemp(prefix="bmh_seedb_")
+            G = 8_000_000
+            gref = rng.integers(0, 4, G, dtype=np.uint8)
+            fa = os.path.join(tmpd, "ref.fa")
+            reflib.write_fasta(fa, "synth", gref)
+            reflib.build_index(fa)
+            idx = reflib.lib().bwa_idx_load(fa.encode(), 7)
+            prim, L2, sl, words, sai, sa = reflib.bwt_arrays(idx)
+            so = reflib.smem_opt_of(reflib.opt_from_params(params))
+            Lr, nr = 150, args.seed_reads
+            pos = rng.integers(0, G - Lr - 8, size=nr)
+            sreads = gref[pos[:, None] + np.arange(Lr)[None, :]]
+            sub = rng.random(sreads.shape) < 0.02
+            sreads = np.where(sub, (sreads + rng.integers(1, 4, sreads.shape)) & 3, sreads).astype(np.uint8)
+            rcm = rng.random(nr) < 0.5
+            sreads[rcm] = 3 - sreads[rcm][:, ::-1]
+            rl = list(sreads)
+            ctx.set_bwt(prim, L2, sl, words, sai, sa)
+            ctx.smem_batch(so, rl[:2000])
+            got = ctx.smem_batch(so, rl)
+            k_smem = ctx.last_kernel_ms()
+            keep = []
+            cb = kswlib.make_cbwt(prim, L2, sl, words, sai, sa, keep)
+            orc = kswlib.load_oracle()
+            orc.orc_fm_extends.restype = C.c_uint64
+            orc.orc_fm_extends(1)
+            nsmp = min(nr, 2000)
+            okf = True
+            for r in range(nsmp):
+                wc, wi = kswlib.orc_smem_calls(cb, so, rl[r])
+                gc, gi = got[r]
+                okf = okf and len(gc) == len(wc) and len(gi) == len(wi) and bool((gi == wi).all()) and bool((gc["ret"] == wc["ret"]).all())
+            ext_per_read = orc.orc_fm_extends(1) / nsmp
+            iv = np.concatenate([x for _, x in got])
+            sl_ = (iv["info"] & 0xffffffff).astype(np.int64) - (iv["info"] >> 32).astype(np.int64)
+            sel = (sl_ >= int(so["min_seed_len"])) & (iv["x2"] <= 10000)
+            x0s, x2s = iv["x0"][sel].astype(np.int64), iv["x2"][sel].astype(np.int64)
+            ks = (np.repeat(x0s, x2s) + (np.arange(int(x2s.sum()), dtype=np.int64) - np.repeat(np.cumsum(x2s) - x2s, x2s))).astype(np.uint64)
+            ctx.sa_batch(ks[:1000])
+            posg = ctx.sa_batch(ks)
+            k_sa = ctx.last_kernel_ms()
+            shim = C.CDLL(os.path.join(kswlib.REF_DIR, "libref_seed_shim.so"))
+            shim.ref_smem_iter_mt.restype = C.c_uint64
+            ncores = os.cpu_count() or 1
+            spool = np.ascontiguousarray(sreads.reshape(-1))
+            off = np.arange(nr, dtype=np.uint64) * Lr
+            lens = np.full(nr, Lr, dtype=np.int32)
+            cs = C.c_uint64(0)
+            bwt_p = C.c_void_p(idx.contents.bwt)
+            a_ = (bwt_p, C.c_int(nr), spool.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p),
+                  C.c_int(int(so["split_len"])), C.c_int(int(so["split_width"])), C.c_int(int(so["start_width"])), C.c_int(ncores), C.byref(cs))
+            shim.ref_smem_iter_mt(*a_)
+            t1 = time.perf_counter()
+            shim.ref_smem_iter_mt(*a_)
+            cpu_smem = time.perf_counter() - t1
+            posc = np.zeros(len(ks), dtype=np.uint64)
+            shim.ref_sa_mt(bwt_p, ks.ctypes.data_as(C.c_void_p), C.c_int(len(ks)), posc.ctypes.data_as(C.c_void_p), C.c_int(ncores))
+            t1 = time.perf_counter()
+            shim.ref_sa_mt(bwt_p, ks.ctypes.data_as(C.c_void_p), C.c_int(len(ks)), posc.ctypes.data_as(C.c_void_p), C.c_int(ncores))
+            cpu_sa = time.perf_counter() - t1
+            seedb = {"kernel": "smem_kernel (bwt_smem1 in smem_next2 order, one lane per read) + sa_kernel (bwt_sa)",
+                     "genome_bp": G, "reads": nr, "smem_kernel_ms": k_smem, "reads_per_s": nr / (k_smem * 1e-3),
+                     "bwt_extend_per_read": ext_per_read,
+                     "algorithmic_GBps": ext_per_read * 2 * 64.0 * nr / (k_smem * 1e-3) / 1e9, "hbm_frac": ext_per_read * 2 * 64.0 * nr / (k_smem * 1e-3) / 8e12,
+                     "sa_lookups": int(len(ks)), "sa_kernel_ms": k_sa, "sa_lookups_per_s": len(ks) / (k_sa * 1e-3),
+                     "parity": ("bit-exact vs oracle (%d reads) and vs the reference's bwt_sa (all look-ups)" % nsmp)
+                     if okf and bool((posc == posg).all()) else "MISMATCH",
+                     "cpu_reference_reads_per_s": nr / cpu_smem, "cpu_reference_sa_lookups_per_s": len(ks) / cpu_sa, "cpu_threads": ncores}
+
     # ---- parity spot-check + CPU baseline (untimed w.r.t. the GPU figure)
     res = d_res.cpu().numpy().view(pkg.EXT_RES)
     out = None
@@ -306,6 +386,7 @@ def main():
             "cpu_baseline": cpu,
             "global_alignment": glb,
             "mate_rescue_sw": swb,
+            "seeding_fmindex": seedb,
             "setup": {"taskgen_s": gen_s},
         }
         if not parity_ok:
