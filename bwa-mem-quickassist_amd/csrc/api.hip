@@ -108,13 +108,15 @@ int bmh_ctx_create(bmh_ctx_t **out, int device)
 	    (e = hipMalloc((void **)&ctx->d_err, sizeof(int))) != hipSuccess || (e = hipMemset(ctx->d_err, 0, sizeof(int))) != hipSuccess ||
 	    (e = hipHostMalloc((void **)&ctx->h_err, sizeof(int), hipHostMallocDefault)) != hipSuccess ||
 	    (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess ||
-	    false) {
+	    (e = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking)) != hipSuccess ||
+	    (e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)) != hipSuccess ||
+	    (e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming)) != hipSuccess) {
 		fprintf(stderr, "[bwamem_hip] context creation failed: %s\n", hipGetErrorString(e));
 		bmh_ctx_destroy(ctx);
 		return BMH_E_NODEVICE;
 	}
 	for (int b = 0; b <= kExtBinsMax; ++b)
-		if (hipEventCreate(&ctx->ev_bin[b]) != hipSuccess) {
+		if (hipEventCreate(&ctx->ev_bin[b]) != hipSuccess || hipEventCreate(&ctx->ev_bin_end[b]) != hipSuccess) {
 			bmh_ctx_destroy(ctx);
 			return BMH_E_NODEVICE;
 		}
@@ -144,7 +146,13 @@ int bmh_ctx_destroy(bmh_ctx_t *ctx)
 	if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
 	if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
 	for (int b = 0; b <= kExtBinsMax; ++b)
+	{
 		if (ctx->ev_bin[b]) (void)hipEventDestroy(ctx->ev_bin[b]);
+		if (ctx->ev_bin_end[b]) (void)hipEventDestroy(ctx->ev_bin_end[b]);
+	}
+	if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+	if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+	if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
 	if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
 	delete ctx;
 	return BMH_OK;
@@ -285,8 +293,8 @@ int bmh_last_extend_bin_ms(bmh_ctx_t *ctx, float ms[6])
 	if (!ctx || !ms) return BMH_E_ARG;
 	for (int b = 0; b < kExtBins; ++b) ms[b] = -1.f;
 	if (!ctx->ev_bin_valid) return BMH_OK;
-	BMH_HIP(ctx, hipEventSynchronize(ctx->ev_bin[kExtBins]));
-	for (int b = 0; b < kExtBins; ++b) BMH_HIP(ctx, hipEventElapsedTime(&ms[b], ctx->ev_bin[b], ctx->ev_bin[b + 1]));
+	BMH_HIP(ctx, hipEventSynchronize(ctx->ev1)); // recorded after both streams joined
+	for (int b = 0; b < kExtBins; ++b) BMH_HIP(ctx, hipEventElapsedTime(&ms[b], ctx->ev_bin[b], ctx->ev_bin_end[b]));
 	return BMH_OK;
 }
 

@@ -41,7 +41,10 @@ struct bmh_ctx {
 	bool timing = false;
 	hipEvent_t ev0 = nullptr, ev1 = nullptr;
 	bool ev_valid = false;
-	hipEvent_t ev_bin[kExtBinsMax + 1] = {}; // boundaries of the extension bins
+	hipEvent_t ev_bin[kExtBinsMax + 1] = {};     // start of each extension bin's kernels
+	hipEvent_t ev_bin_end[kExtBinsMax + 1] = {}; // ... and their end (bins run on two streams, see launch_extend)
+	hipStream_t aux_stream = nullptr;            // the few long flanks (bins 3-5) run beside the lane kernels
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	bool ev_bin_valid = false;
 	std::string last_error;
 	bmh_driver_stats_t dstats{};

@@ -161,13 +161,25 @@ int launch_extend(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_t
 	if ((rc = sort_tasks_finish(ctx, n, d_order, (unsigned)cg))) return rc;
 	const bool tm = ctx->timing;
 	if (tm) BMH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-	for (int b = 0; b < kExtBins; ++b) {
-		if (tm) BMH_HIP(ctx, hipEventRecord(ctx->ev_bin[b], ctx->stream));
+	// Bins 0-2 (lane-per-task kernels, almost all tasks) run on the caller's stream; the few long flanks of bins 3-5
+	// (few waves, each running for many rows) run BESIDE them on a second stream instead of as a serial tail.
+	hipStream_t main_s = ctx->stream;
+	BMH_HIP(ctx, hipEventRecord(ctx->ev_fork, main_s));
+	BMH_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
+	static const int order[kExtBins] = {3, 4, 5, 0, 1, 2};
+	for (int k = 0; k < kExtBins; ++k) {
+		const int b = order[k];
+		ctx->stream = b >= 3 ? ctx->aux_stream : main_s; // the launchers enqueue on ctx->stream
+		if (tm) {
+			rc = (int)hipEventRecord(ctx->ev_bin[b], ctx->stream);
+			if (rc) { ctx->stream = main_s; return set_hip_error(ctx, (hipError_t)rc, "hipEventRecord"); }
+		}
 		const uint32_t *lst = lists + (size_t)b * N, *cnt = counts + b;
 		const int qlo = b == 0 ? 0 : 16 << b; // bins 0..4 hold qlen <= 32,64,128,256,512
-		if (b < 5 && (mode == 1 || qmax <= qlo)) continue; // provably empty bin
 		rc = BMH_OK;
-		if (b <= 2) {
+		if (b < 5 && (mode == 1 || qmax <= qlo)) {
+			// provably empty bin
+		} else if (b <= 2) {
 			if (mode == 0 || mode == 4) rc = launch_extend_lane(ctx, 32 << b, d_pool, d_tasks, n, d_res, lst, cnt);
 			else if (mode == 3) rc = launch_extend_grp(ctx, 2 << b, d_pool, d_tasks, n, d_res, lst, cnt);
 			else rc = launch_extend_reg(ctx, b == 2 ? 2 : 1, d_pool, d_tasks, n, d_res, lst, cnt);
@@ -177,11 +189,14 @@ int launch_extend(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_t
 				if (!rc) rc = launch_extend_reg(ctx, 4, d_pool, d_tasks, n < kLanexMinTasks ? n : kLanexMinTasks, d_res, lst, cnt, kLanexMinTasks);
 			} else rc = launch_extend_reg(ctx, 4, d_pool, d_tasks, n, d_res, lst, cnt);
 		} else if (b == 4 && mode == 4) rc = launch_extend_lanex(ctx, 4, d_pool, d_tasks, n, d_res, lst, cnt, 0);
-		else rc = launch_extend_lds(ctx, d_pool, d_tasks, mode != 1 && qmax <= 256 ? 4096 : n, d_res, lst, cnt, qmax);
-		if (rc) return rc;
+		else if (b == 5 || (b == 4 && mode != 4)) rc = b == 5 ? launch_extend_lds(ctx, d_pool, d_tasks, mode != 1 && qmax <= 256 ? 4096 : n, d_res, lst, cnt, qmax) : BMH_OK;
+		if (!rc && tm) rc = (int)hipEventRecord(ctx->ev_bin_end[b], ctx->stream) ? BMH_E_HIP : BMH_OK;
+		if (rc) { ctx->stream = main_s; return rc; }
 	}
+	ctx->stream = main_s;
+	BMH_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->aux_stream));
+	BMH_HIP(ctx, hipStreamWaitEvent(main_s, ctx->ev_join, 0));
 	if (tm) {
-		BMH_HIP(ctx, hipEventRecord(ctx->ev_bin[kExtBins], ctx->stream));
 		BMH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
 		ctx->ev_valid = ctx->ev_bin_valid = true;
 	}
