@@ -1,6 +1,6 @@
 // sw_generic.hip -- local Smith-Waterman (ksw_align2, reference bwa-0.7.8/ksw.c:341-364) for tasks of ANY size:
-// one lane per task, the DP row in an HBM slab laid out [column][lane] so that the 64 lanes of a wave touch one
-// 256-byte line per column.  This is the catch-all behind the register kernels of sw_lane.hip: simple, exact, slow.
+// one lane per task, the DP row in an HBM slab laid out [8-column chunk][lane][8] so that a lane moves 8 columns with
+// one 32-byte access and the 64 lanes of a wave touch 2 KB contiguously.  This is the catch-all behind the register kernels of sw_lane.hip: simple, exact, slow.
 //
 // What is computed (derived from ksw_qinit/ksw_u8/ksw_i16, ksw.c:62-331, and pinned against them by the oracle):
 // the striped SSE2 code equals the textbook affine-gap recurrence over the query PADDED to Q = p*slen columns
@@ -37,38 +37,56 @@ __device__ __forceinline__ int sw_tbase(const SwSeq &s, const DevParams &P, int 
 	return c > 4 ? 4 : c;
 }
 
+// he / qc hold 8 columns per lane contiguously ([chunk][lane][8]): one 32-byte and one 8-byte access per 8 cells, the 8
+// cells themselves are computed from registers.
 __device__ SwCore sw_pass_generic(const SwSeq &seq, const DevParams &P, const int *smat, bool byte_mode, int qlen,
                                   int tlen, int minsc, int endsc, uint32_t *he, uint8_t *qc, uint16_t *rm)
 {
 	const int p = byte_mode ? 16 : 8;
-	const int slen = (qlen + p - 1) / p, Q = slen * p;
+	const int slen = (qlen + p - 1) / p, Q = slen * p, NC = Q / 8; // Q is a multiple of 8
 	const int o_del = P.o_del, e_del = P.e_del, o_ins = P.o_ins, e_ins = P.e_ins;
 	SwCore r;
 	r.score = 0, r.te = -1, r.qe = -1, r.score2 = -1, r.te2 = -1;
-	for (int j = 0; j < Q; ++j) {
-		qc[(size_t)j * 64] = (uint8_t)(j < qlen ? sw_qbase(seq, j) : 5); // code 5 = pad column, scores 0 (ksw.c:98,107)
-		he[(size_t)j * 64] = 0;
+	for (int c = 0; c < NC; ++c) {
+		uint32_t lo = 0, hi = 0;
+		for (int k = 0; k < 8; ++k) {
+			const int j = 8 * c + k;
+			const uint32_t code = (uint32_t)(j < qlen ? sw_qbase(seq, j) : 5); // code 5 = pad column, scores 0 (ksw.c:98,107)
+			if (k < 4) lo |= code << (8 * k);
+			else hi |= code << (8 * (k - 4));
+		}
+		*(uint2 *)(qc + (size_t)c * 512) = make_uint2(lo, hi);
+		uint4 *h = (uint4 *)(he + (size_t)c * 512);
+		h[0] = make_uint4(0, 0, 0, 0), h[1] = make_uint4(0, 0, 0, 0);
 	}
 	int gmax = 0, te = -1, qe = -1, nrows = 0;
 	bool ovf = false;
 	for (int i = 0; i < tlen && slen > 0; ++i) {
 		const int *row = smat + sw_tbase(seq, P, i) * 8;
 		int fseg = 0, ffull = 0, diag = 0, imax = 0, arg = -1, js = 0;
-		for (int j = 0; j < Q; ++j) {
-			const uint32_t x = he[(size_t)j * 64];
-			const int hold = (int)(x & 0xffff), e = (int)(x >> 16);
-			const int mm = max(diag + row[qc[(size_t)j * 64]], 0);
-			if (js == 0) fseg = 0; // every vector lane of the reference starts its segment with f = 0 (ksw.c:139)
-			js = js + 1 == slen ? 0 : js + 1;
-			const int hpre = max(max(mm, e), fseg); // what the main loop stores, ksw.c:151-154
-			const int h = max(hpre, ffull);         // after the lazy-F loop, ksw.c:165-176
-			if (h > imax) imax = h, arg = j;        // ties -> smallest query index, ksw.c:204-206
-			diag = hold;
-			const int en = max(max(e, max(hpre - o_del, 0)) - e_del, 0); // ksw.c:155-158, from the uncorrected H
-			const int t = max(hpre - o_ins, 0);
-			fseg = max(max(fseg, t) - e_ins, 0); // ksw.c:160-162
-			ffull = max(max(ffull, t) - e_ins, 0);
-			he[(size_t)j * 64] = (uint32_t)en << 16 | (uint32_t)h;
+		for (int c = 0; c < NC; ++c) {
+			uint4 *hp4 = (uint4 *)(he + (size_t)c * 512);
+			const uint4 h0 = hp4[0], h1 = hp4[1];
+			const uint2 qq = *(const uint2 *)(qc + (size_t)c * 512);
+			uint32_t x[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+			for (int k = 0; k < 8; ++k) {
+				const int code = (int)((k < 4 ? qq.x >> (8 * k) : qq.y >> (8 * (k - 4))) & 0xff);
+				const int hold = (int)(x[k] & 0xffff), e = (int)(x[k] >> 16);
+				const int mm = max(diag + row[code], 0);
+				if (js == 0) fseg = 0; // every vector lane of the reference starts its segment with f = 0 (ksw.c:139)
+				js = js + 1 == slen ? 0 : js + 1;
+				const int hpre = max(max(mm, e), fseg); // what the main loop stores, ksw.c:151-154
+				const int h = max(hpre, ffull);         // after the lazy-F loop, ksw.c:165-176
+				if (h > imax) imax = h, arg = 8 * c + k; // ties -> smallest query index, ksw.c:204-206
+				diag = hold;
+				const int en = max(max(e, max(hpre - o_del, 0)) - e_del, 0); // ksw.c:155-158, from the uncorrected H
+				const int t = max(hpre - o_ins, 0);
+				fseg = max(max(fseg, t) - e_ins, 0); // ksw.c:160-162
+				ffull = max(max(ffull, t) - e_ins, 0);
+				x[k] = (uint32_t)en << 16 | (uint32_t)h;
+			}
+			hp4[0] = make_uint4(x[0], x[1], x[2], x[3]), hp4[1] = make_uint4(x[4], x[5], x[6], x[7]);
 		}
 		nrows = i + 1;
 		if (rm) rm[(size_t)i * 64] = (uint16_t)imax;
@@ -102,9 +120,9 @@ __global__ __launch_bounds__(64) void sw_generic_kernel(const uint8_t *__restric
 	__syncthreads();
 	const long long cnt = count ? (long long)*count : n;
 	uint8_t *base = slab + (size_t)blockIdx.x * (size_t)slab_stride;
-	uint32_t *he = (uint32_t *)base + lane;                                        // [qcap][64] u32
+	uint32_t *he = (uint32_t *)base + lane * 8;                                    // [qcap/8][64][8] u32
 	uint16_t *rm = (uint16_t *)(base + (size_t)qcap * 256) + lane;                 // [tcap][64] u16
-	uint8_t *qc = base + (size_t)qcap * 256 + (size_t)tcap * 128 + lane;           // [qcap][64] u8
+	uint8_t *qc = base + (size_t)qcap * 256 + (size_t)tcap * 128 + lane * 8;       // [qcap/8][64][8] u8
 	for (long long c0 = (long long)blockIdx.x * 64; c0 < cnt; c0 += (long long)gridDim.x * 64) {
 		const long long pos = c0 + lane;
 		if (pos >= cnt) continue;
