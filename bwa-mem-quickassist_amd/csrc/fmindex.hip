@@ -346,7 +346,9 @@ int bmh_smem_batch(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const b
 	std::vector<uint8_t> pool(bytes + 16, 0);
 	for (int r = 0; r < n_reads; ++r)
 		if (reads[r].l_seq) memcpy(pool.data() + off[(size_t)r], reads[r].seq, (size_t)reads[r].l_seq);
-	const int grid = (int)std::min<long long>(((long long)n_reads + 63) / 64, 4096), lcap = lmax + 2;
+	const int lcap = lmax + 2;
+	int grid = (int)std::min<long long>(((long long)n_reads + 63) / 64, 4096);
+	while (grid > 1 && (size_t)grid * 3 * (size_t)lcap * 64 * sizeof(Intv) > ((size_t)2 << 30)) grid /= 2; // stacks: at most 2 GB
 	// device outputs grow until everything fits (the totals are data dependent)
 	size_t d_calls = std::max<size_t>((size_t)n_reads * 8, 1024), d_intv = std::max<size_t>((size_t)n_reads * 32, 4096);
 	std::vector<bmh_smem_call_t> h_calls;
