@@ -82,7 +82,9 @@ def _run(fa, fqs, out, extra, preload):
 
 
 @pytest.mark.parametrize("extra", [["-t", "4", "-b", "512"], ["-t", "2", "-b", "64", "-w", "10", "-d", "30"],
-                                   ["-t", "3", "-b", "1000", "-A", "2", "-B", "6", "-O", "8,6", "-E", "2,3"]])
+                                   ["-t", "3", "-b", "1000", "-A", "2", "-B", "6", "-O", "8,6", "-E", "2,3"],
+                                   # seeding options: shorter seeds, re-seeding of every long match, few occurrences
+                                   ["-t", "4", "-b", "300", "-k", "14", "-r", "1.0", "-c", "20"]])
 def test_se_sam_identical(genome, extra):
     rng, tmp, fa, ref = genome
     reads = _sim_reads(rng, ref, 1500, 150, False)[0] + _sim_reads(rng, ref, 700, 250, True)[0] + \
@@ -137,3 +139,45 @@ def test_pe_mate_rescue_sam_identical(genome):
     m = re.findall(r"mate rescue: (\d+) pairs, (\d+) ksw_align2 calls in (\d+) GPU rounds, (\d+) pool bytes", _run.last_stderr)
     assert m and sum(int(x[1]) for x in m) > 100 and all(int(x[2]) <= 12 for x in m)
     assert all(int(x[3]) <= int(x[0]) * 2 * 151 + 64 for x in m), "with the reference resident only the reads are shipped"
+
+
+def test_multi_contig_reference_sam_identical():
+    """Three contigs of different length, reads that hang over contig ends and reads with N: exercises bwa_fix_xref2
+    (reference bwa.c:179) in front of the CIGAR batch and the rid/pos conversion behind it, SE and PE."""
+    rng = np.random.default_rng(515151)
+    tmp = tempfile.mkdtemp(prefix="bmh_mc_")
+    contigs = [kswgen.rand_seq(rng, n) for n in (90000, 30011, 6007)]
+    fa = os.path.join(tmp, "mc.fa")
+    with open(fa, "w") as f:
+        for k, c in enumerate(contigs):
+            f.write(f">ctg{k} some description\n")
+            s = "".join("ACGT"[b] for b in c)
+            for i in range(0, len(s), 70):
+                f.write(s[i:i + 70] + "\n")
+    reflib.build_index(fa)
+    whole = np.concatenate(contigs)
+    reads = []
+    for _ in range(900):
+        L = int(rng.choice([100, 150, 151, 220]))
+        pos = int(rng.integers(0, len(whole) - L))  # may straddle a contig boundary
+        rd = kswgen.mutate(rng, whole[pos:pos + L + 10], 0.02, 0.003, 0.003, 3)[:L].copy()
+        if rng.random() < 0.2:
+            rd[rng.random(len(rd)) < 0.02] = 4
+        if rng.random() < 0.5:
+            rd = np.where(rd[::-1] > 3, 4, 3 - rd[::-1]).astype(np.uint8)
+        reads.append(rd)
+    for b in (0, 90000 - 70, 90000 - 20, 120011 - 75, len(whole) - 150):  # deliberately across / at the ends
+        reads.append(whole[b:b + 150].copy())
+    fq = os.path.join(tmp, "mc.fq")
+    reflib.write_fastq(fq, reads)
+    extra = ["-t", "3", "-b", "200"]
+    ref_sam = _run(fa, [fq], os.path.join(tmp, "ref.sam"), extra, False)
+    dut_sam = _run(fa, [fq], os.path.join(tmp, "dut.sam"), extra, True)
+    assert len(ref_sam) > len(reads) and ref_sam == dut_sam
+    r1, r2 = _sim_reads(rng, whole, 500, 125, False, pair=True, rescue=0.4)
+    f1, f2 = os.path.join(tmp, "mc_1.fq"), os.path.join(tmp, "mc_2.fq")
+    reflib.write_fastq(f1, r1, "q")
+    reflib.write_fastq(f2, r2, "q")
+    ref_sam = _run(fa, [f1, f2], os.path.join(tmp, "ref_pe.sam"), extra, False)
+    dut_sam = _run(fa, [f1, f2], os.path.join(tmp, "dut_pe.sam"), extra, True)
+    assert len(ref_sam) >= 1000 and ref_sam == dut_sam
