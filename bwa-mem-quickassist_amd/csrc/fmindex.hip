@@ -350,7 +350,10 @@ int bmh_smem_batch(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const b
 	int grid = (int)std::min<long long>(((long long)n_reads + 63) / 64, 4096);
 	while (grid > 1 && (size_t)grid * 3 * (size_t)lcap * 64 * sizeof(Intv) > ((size_t)2 << 30)) grid /= 2; // stacks: at most 2 GB
 	// device outputs grow until everything fits (the totals are data dependent)
-	size_t d_calls = std::max<size_t>((size_t)n_reads * 8, 1024), d_intv = std::max<size_t>((size_t)n_reads * 32, 4096);
+	// sized from the densest batch this context has seen (calls / intervals per base), so that a steady stream of
+	// batches does not run the kernel twice
+	size_t d_calls = std::max<size_t>((size_t)(ctx->smem_calls_per_base * 1.25 * (double)bytes) + 1024, 1024);
+	size_t d_intv = std::max<size_t>((size_t)(ctx->smem_intv_per_base * 1.25 * (double)bytes) + 4096, 4096);
 	std::vector<bmh_smem_call_t> h_calls;
 	std::vector<uint32_t> h_read;
 	std::vector<Intv> h_intv;
@@ -378,6 +381,8 @@ int bmh_smem_batch(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const b
 		}
 		BMH_HIP(ctx, hipMemcpyAsync(totals, d, 16, hipMemcpyDeviceToHost, ctx->stream));
 		BMH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		ctx->smem_calls_per_base = std::max(ctx->smem_calls_per_base, (double)totals[0] / (double)std::max<size_t>(bytes, 1));
+		ctx->smem_intv_per_base = std::max(ctx->smem_intv_per_base, (double)totals[1] / (double)std::max<size_t>(bytes, 1));
 		if (totals[0] <= d_calls && totals[1] <= d_intv) {
 			h_calls.resize((size_t)totals[0]), h_read.resize((size_t)totals[0]), h_intv.resize((size_t)totals[1]);
 			if (totals[0]) {

@@ -64,6 +64,7 @@ extern int mem_chain2aln_short(const void *opt, int64_t l_pac, const uint8_t *pa
 extern int mem_sort_and_dedup(int n, bmh_alnreg_t *a, float mask_level_redun);
 extern int mem_test_and_remove_exact(const void *opt, int n, bmh_alnreg_t *a, int qlen);
 extern unsigned char nst_nt4_table[256];
+extern double cputime(void), realtime(void); /* utils.c */
 
 typedef struct {
 	const ref_mem_opt_t *opt;
@@ -106,6 +107,7 @@ typedef struct {
 	size_t n_sa;
 	long long smem_hit, smem_miss, sa_hit, sa_miss;
 } qa_seed_t;
+static double g_seed_density[2] = {0.06, 0.35};
 static __thread qa_seed_t *qa_seed; /* the batch this thread is chaining, or NULL */
 static __thread int qa_seed_cur;    /* index of the read mem_chain is working on */
 
@@ -135,7 +137,10 @@ static void qa_seed_batch_begin(bmh_ctx_t *ctx, const ref_mem_opt_t *opt, const 
 	S = (qa_seed_t *)calloc(1, sizeof(*S));
 	S->bwt = bwt, S->n_reads = n, S->reads = reads;
 	S->call_off = (uint32_t *)malloc(4 * ((size_t)n + 1)), S->intv_off = (uint64_t *)malloc(8 * ((size_t)n + 1));
-	for (call_cap = 2 * tot / 8 + 64 * (size_t)n + 64, intv_cap = 8 * tot + 1024;; call_cap *= 2, intv_cap *= 2) {
+	/* output arrays sized from the densest batch seen so far in this process (calls / intervals per base) */
+	for (call_cap = (size_t)(g_seed_density[0] * 1.3 * (double)tot) + 4 * (size_t)n + 64,
+	    intv_cap = (size_t)(g_seed_density[1] * 1.3 * (double)tot) + 1024;;
+	     call_cap *= 2, intv_cap *= 2) {
 		S->calls = (bmh_smem_call_t *)malloc(sizeof(bmh_smem_call_t) * call_cap);
 		S->intv = (bmh_smem_intv_t *)malloc(sizeof(bmh_smem_intv_t) * intv_cap);
 		rc = bmh_smem_batch(ctx, &so, n, reads, S->call_off, S->calls, call_cap, S->intv_off, S->intv, intv_cap);
@@ -143,6 +148,11 @@ static void qa_seed_batch_begin(bmh_ctx_t *ctx, const ref_mem_opt_t *opt, const 
 		free(S->calls), free(S->intv);
 	}
 	if (rc) bmh_tls_die(bmh_last_error(ctx), rc);
+	if (tot) { /* (a benign race: statistics that only size buffers) */
+		const double dc = (double)S->call_off[n] / (double)tot, di = (double)S->intv_off[n] / (double)tot;
+		if (dc > g_seed_density[0]) g_seed_density[0] = dc;
+		if (di > g_seed_density[1]) g_seed_density[1] = di;
+	}
 	/* the suffix-array entries mem_insert_seed will ask for (bwamem.c:218-225): every occurrence of every interval that
 	 * is long and rare enough -- taken over ALL returned intervals, a superset of the merged list it walks */
 	for (k = 0; k < S->intv_off[n]; ++k) {
@@ -226,6 +236,8 @@ uint64_t bwt_sa(const void *bwt, uint64_t k)
 	return next(bwt, k);
 }
 
+static long long g_p1_us[5]; /* phase 1, thread-microseconds: wait for a GPU slot, seeding batch, chaining (host), wait, extension batch */
+
 bmh_alnreg_v *mem_align1_core_batched(const ref_mem_opt_t *opt, const void *bwt, const ref_bntseq_head_t *bns,
                                       const uint8_t *pac, ref_bseq1_t *seqs, int start, int batch_size)
 {
@@ -235,6 +247,7 @@ bmh_alnreg_v *mem_align1_core_batched(const ref_mem_opt_t *opt, const void *bwt,
 	bmh_params_t p;
 	bmh_ctx_t *ctx;
 	pre_ud_t ud;
+	double tq[6];
 	int b, i, rc;
 
 	for (b = 0; b < batch_size; ++b) { /* bwamem.c:1093-1094 */
@@ -246,19 +259,24 @@ bmh_alnreg_v *mem_align1_core_batched(const ref_mem_opt_t *opt, const void *bwt,
 	p.o_del = opt->o_del, p.e_del = opt->e_del, p.o_ins = opt->o_ins, p.e_ins = opt->e_ins, p.zdrop = opt->zdrop;
 	p.a = opt->a, p.w = opt->w, p.pen_clip5 = opt->pen_clip5, p.pen_clip3 = opt->pen_clip3;
 	memcpy(p.mat, opt->mat, 25);
+	tq[0] = realtime();
 	gpu_enter(); /* contexts are taken inside the limited section, so no more of them exist than can be busy */
+	tq[1] = realtime();
 	ctx = bmh_pool_get(&p);
 	qa_seed_batch_begin(ctx, opt, (const ref_bwt_t *)bwt, batch_size, reads); /* SMEMs + suffix-array look-ups of the batch on the GPU */
 	bmh_pool_put(ctx);
 	gpu_leave();
+	tq[2] = realtime();
 	for (b = 0; b < batch_size; ++b) { /* chaining stays the reference's own code: bwamem.c:1095-1097 */
 		qa_seed_cur = b;
 		chn[b] = mem_chain(opt, bwt, bns->l_pac, reads[b].l_seq, reads[b].seq);
 		chn[b].n = (size_t)mem_chain_flt(opt, (int)chn[b].n, chn[b].a);
 	}
 	qa_seed_batch_end();
+	tq[3] = realtime();
 	ud.opt = opt, ud.l_pac = bns->l_pac, ud.pac = pac, ud.reads = reads, ud.chains = chn;
 	gpu_enter();
+	tq[4] = realtime();
 	ctx = bmh_pool_get(&p);
 	{ /* reference resident in HBM, shared by all contexts: the kernels do bns_get_seq themselves.  BMH_PAC_RESIDENT=0
 	   * falls back to host-decoded windows in the pool. */
@@ -269,6 +287,16 @@ bmh_alnreg_v *mem_align1_core_batched(const ref_mem_opt_t *opt, const void *bwt,
 		bmh_tls_die(bmh_last_error(ctx), rc);
 	bmh_pool_put(ctx);
 	gpu_leave();
+	tq[5] = realtime();
+	{ /* thread-seconds per stage, summed over the run (BMH_VERBOSE prints them per chunk) */
+		static const int a_[5] = {0, 1, 2, 3, 4};
+		int k;
+		for (k = 0; k < 5; ++k) {
+			const double d = tq[a_[k] + 1] - tq[a_[k]];
+			long long us = (long long)(d * 1e6);
+			__sync_fetch_and_add(&g_p1_us[k], us);
+		}
+	}
 
 	for (b = 0; b < batch_size; ++b) { /* CPU stages after the path, unchanged: bwamem.c:1106,1112-1117 */
 		for (i = 0; i < (int)chn[b].n; ++i) free(chn[b].a[i].seeds);
@@ -302,7 +330,6 @@ extern void kt_for_batch(int n_threads, void (*func)(void *, int, int, int), voi
 extern void mem_pestat(const void *opt, int64_t l_pac, int n, const bmh_alnreg_v *regs, bmh_pestat_t pes[4]); /* bwamem_pair.c:46 */
 extern int mem_sam_pe(const void *opt, const void *bns, const uint8_t *pac, const bmh_pestat_t pes[4], uint64_t id,
                       ref_bseq1_t s[2], bmh_alnreg_v a[2]);                                                 /* bwamem_pair.c:238 */
-extern double cputime(void), realtime(void); /* utils.c */
 extern int bwa_verbose;
 
 typedef struct {
@@ -616,6 +643,9 @@ void mem_process_seqs(const ref_mem_opt_t *opt, const void *bwt, const ref_bntse
 	if (pe) kt_for(opt->n_threads, qa_worker2_pe, &w, n >> 1); /* bwamem.c:1319 */
 	else kt_for(opt->n_threads, qa_worker2_se, &w, n);
 	t_[4] = realtime();
+	if (getenv("BMH_VERBOSE"))
+		fprintf(stderr, "[bwamem_hip] phase 1 thread-seconds so far: wait %.3f, seeding batch %.3f, chaining on the host %.3f, wait %.3f, extension batch %.3f\n",
+		        g_p1_us[0] * 1e-6, g_p1_us[1] * 1e-6, g_p1_us[2] * 1e-6, g_p1_us[3] * 1e-6, g_p1_us[4] * 1e-6);
 	if (getenv("BMH_VERBOSE"))
 		fprintf(stderr, "[bwamem_hip] seeding: bwt_smem1 %lld from the batch / %lld on the host, bwt_sa %lld / %lld\n", g_seed_stats[0],
 		        g_seed_stats[1], g_seed_stats[2], g_seed_stats[3]);
