@@ -8,6 +8,8 @@
 // the reference's 256-entry byte table (same numbers).  This stage is the one part of the pipeline that is bound by
 // random memory access rather than by instruction issue.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -121,23 +123,30 @@ __device__ int fm_smem1(const DevBwt &B, int len, const uint8_t *q, int x, int m
 	const int ret = (int)curr[0].info;
 	{ const Stack t = curr; curr = prev, prev = t; }
 	np = nc;
+	uint64_t mem_start = 0; // mem[nm-1].info >> 32, kept in a register (it is tested once per interval and step)
 	for (i = x - 1; i >= -1; --i) { // backward search for MEMs
 		const int c = i < 0 ? -1 : q[i] < 4 ? q[i] : -1;
+		uint64_t last_x2 = 0; // curr[nc-1].x2, likewise
 		nc = 0;
 		for (int j = 0; j < np; ++j) {
 			const Intv p = prev[j];
-			fm_extend(B, p, ok, true);
-			const Intv o = c <= 0 ? ok[0] : c == 1 ? ok[1] : c == 2 ? ok[2] : ok[3];
-			if (c < 0 || o.x2 < (uint64_t)min_intv) {
-				if (nc == 0 && (nm == 0 || (uint64_t)(i + 1) < mem[nm - 1].info >> 32)) {
+			bool keep = c < 0; // the start of the read or an ambiguous base ends every interval: no extension needed
+			Intv o{};
+			if (!keep) {
+				fm_extend(B, p, ok, true);
+				o = c == 0 ? ok[0] : c == 1 ? ok[1] : c == 2 ? ok[2] : ok[3];
+				keep = o.x2 < (uint64_t)min_intv;
+			}
+			if (keep) {
+				if (nc == 0 && (nm == 0 || (uint64_t)(i + 1) < mem_start)) {
 					Intv m = p;
 					m.info |= (uint64_t)(i + 1) << 32;
-					mem[nm++] = m;
+					mem[nm++] = m, mem_start = (uint64_t)(i + 1);
 				}
-			} else if (nc == 0 || o.x2 != curr[nc - 1].x2) {
+			} else if (nc == 0 || o.x2 != last_x2) {
 				Intv m = o;
 				m.info = p.info;
-				curr[nc++] = m;
+				curr[nc++] = m, last_x2 = o.x2;
 			}
 		}
 		if (nc == 0) break;
@@ -153,12 +162,16 @@ __global__ __launch_bounds__(64) void smem_kernel(DevBwt B, const uint8_t *__res
                                                   int n_reads, bmh_smem_opt_t O, Intv *scratch, int lcap,
                                                   bmh_smem_call_t *calls, uint32_t *call_read, unsigned long long *cursors,
                                                   unsigned long long call_cap, Intv *intv, unsigned long long intv_cap,
-                                                  int *overflow)
+                                                  int *overflow, int lanes)
 {
+	// `lanes` (a power of two <= 64) reads per wave: the reads of a wave sit in different loops of bwt_smem1 most of the
+	// time and the wave pays for every path in turn, so a batch too small to fill the chip is spread over more, emptier
+	// waves -- its latency then is that of a few reads' paths, not of 64
 	const int lane = threadIdx.x;
+	if (lane >= lanes) return;
 	Intv *slab = scratch + (size_t)blockIdx.x * 3 * (size_t)lcap * 64 + lane;
 	const Stack s0{slab}, s1{slab + (size_t)lcap * 64}, sm{slab + 2 * (size_t)lcap * 64};
-	for (long long r = (long long)blockIdx.x * 64 + lane; r < n_reads; r += (long long)gridDim.x * 64) {
+	for (long long r = (long long)blockIdx.x * lanes + lane; r < n_reads; r += (long long)gridDim.x * lanes) {
 		const uint8_t *q = pool + read_off[r];
 		const int len = read_len[r];
 		const int split_len = min(O.split_len, len); // bwamem.c:213
@@ -332,6 +345,9 @@ int bmh_smem_batch(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const b
 	}
 	if (n_reads == 0) return BMH_OK;
 	const DevBwt &B = ((bmh_bwt_binding *)ctx->bwt_bind)->dev;
+	const bool trace = getenv("BMH_SMEM_TRACE") != nullptr;
+	auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+	double tt[6] = {now(), 0, 0, 0, 0, 0};
 	int rc, lmax = 1;
 	size_t bytes = 0;
 	std::vector<uint64_t> off((size_t)n_reads);
@@ -347,7 +363,9 @@ int bmh_smem_batch(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const b
 	for (int r = 0; r < n_reads; ++r)
 		if (reads[r].l_seq) memcpy(pool.data() + off[(size_t)r], reads[r].seq, (size_t)reads[r].l_seq);
 	const int lcap = lmax + 2;
-	int grid = (int)std::min<long long>(((long long)n_reads + 63) / 64, 4096);
+	int lanes = 64; // reads per wave: fewer when the batch cannot fill the chip anyway (see smem_kernel)
+	if (const char *e = getenv("BMH_SMEM_LANES")) lanes = atoi(e) >= 8 && atoi(e) <= 64 ? atoi(e) : 64; // (A/B knob; fewer measured slower)
+	int grid = (int)std::min<long long>(((long long)n_reads + lanes - 1) / lanes, 4096);
 	while (grid > 1 && (size_t)grid * 3 * (size_t)lcap * 64 * sizeof(Intv) > ((size_t)2 << 30)) grid /= 2; // stacks: at most 2 GB
 	// device outputs grow until everything fits (the totals are data dependent)
 	// sized from the densest batch this context has seen (calls / intervals per base), so that a steady stream of
@@ -358,6 +376,7 @@ int bmh_smem_batch(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const b
 	std::vector<uint32_t> h_read;
 	std::vector<Intv> h_intv;
 	unsigned long long totals[2] = {0, 0};
+	tt[1] = now();
 	for (int attempt = 0; attempt < 6; ++attempt) {
 		const size_t hdr = 64, o_pool = hdr, o_off = o_pool + ((bytes + 16 + 63) & ~(size_t)63), o_len = o_off + (size_t)n_reads * 8,
 		             o_calls = (o_len + (size_t)n_reads * 4 + 63) & ~(size_t)63, o_cr = o_calls + d_calls * sizeof(bmh_smem_call_t),
@@ -373,7 +392,7 @@ int bmh_smem_batch(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const b
 		hipLaunchKernelGGL(smem_kernel, dim3((unsigned)grid), dim3(64), 0, ctx->stream, B, (const uint8_t *)(d + o_pool),
 		                   (const uint64_t *)(d + o_off), (const int *)(d + o_len), n_reads, *o, (Intv *)ctx->d_sw.p, lcap,
 		                   (bmh_smem_call_t *)(d + o_calls), (uint32_t *)(d + o_cr), (unsigned long long *)d,
-		                   (unsigned long long)d_calls, (Intv *)(d + o_intv), (unsigned long long)d_intv, (int *)(d + 16));
+		                   (unsigned long long)d_calls, (Intv *)(d + o_intv), (unsigned long long)d_intv, (int *)(d + 16), lanes);
 		BMH_HIP(ctx, hipGetLastError());
 		if (ctx->timing) {
 			BMH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
@@ -383,6 +402,7 @@ int bmh_smem_batch(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const b
 		BMH_HIP(ctx, hipStreamSynchronize(ctx->stream));
 		ctx->smem_calls_per_base = std::max(ctx->smem_calls_per_base, (double)totals[0] / (double)std::max<size_t>(bytes, 1));
 		ctx->smem_intv_per_base = std::max(ctx->smem_intv_per_base, (double)totals[1] / (double)std::max<size_t>(bytes, 1));
+		tt[2] = now();
 		if (totals[0] <= d_calls && totals[1] <= d_intv) {
 			h_calls.resize((size_t)totals[0]), h_read.resize((size_t)totals[0]), h_intv.resize((size_t)totals[1]);
 			if (totals[0]) {
@@ -400,6 +420,7 @@ int bmh_smem_batch(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const b
 		                  " intervals do not fit the caller's arrays";
 		return BMH_E_CIGAR_CAP;
 	}
+	tt[3] = now();
 	// the device appended in completion order; put every read's calls back in call order and its intervals behind one another
 	std::vector<uint32_t> cnt((size_t)n_reads + 1, 0);
 	for (size_t c = 0; c < h_calls.size(); ++c) ++cnt[(size_t)h_read[c] + 1];
@@ -418,6 +439,10 @@ int bmh_smem_batch(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const b
 		used += local;
 	}
 	intv_off[n_reads] = used;
+	tt[4] = now();
+	if (trace)
+		fprintf(stderr, "[bwamem_hip] bmh_smem_batch %d reads: prepare %.1f ms, upload+kernel %.1f ms, download %.1f ms, reorder %.1f ms\n", n_reads,
+		        (tt[1] - tt[0]) * 1e3, (tt[2] - tt[1]) * 1e3, (tt[3] - tt[2]) * 1e3, (tt[4] - tt[3]) * 1e3);
 	return BMH_OK;
 }
 

@@ -42,6 +42,24 @@ static void gpu_enter(void)
 }
 static void gpu_leave(void) { sem_post(&g_gpu_sem); }
 
+/* When the shim is loaded: create the contexts the run will use in the background, while the host program parses its
+ * arguments and loads its index ($BMH_PREWARM=0 turns this off). */
+static void *prewarm_thread(void *arg)
+{
+	const char *e = getenv("BMH_GPU_CONCURRENCY");
+	(void)arg;
+	bmh_pool_prewarm(e && atoi(e) > 0 ? atoi(e) : 8);
+	return 0;
+}
+__attribute__((constructor)) static void qa_shim_loaded(void)
+{
+	const char *e = getenv("BMH_PREWARM"), *pl = getenv("LD_PRELOAD");
+	pthread_t t;
+	if (e && e[0] == '0') return;
+	if (!pl || !strstr(pl, "libbwamem_hip_dropin")) return; /* only when preloaded into a host program, not when merely dlopen()ed */
+	if (pthread_create(&t, 0, prewarm_thread, 0) == 0) pthread_detach(t);
+}
+
 typedef struct { /* mem_opt_t of the fork, bwamem.h:21-48 */
 	int a, b, o_del, e_del, o_ins, e_ins, pen_unpaired, pen_clip5, pen_clip3, w, zdrop;
 	int T, flag, min_seed_len;
@@ -108,6 +126,7 @@ typedef struct {
 	long long smem_hit, smem_miss, sa_hit, sa_miss;
 } qa_seed_t;
 static double g_seed_density[2] = {0.06, 0.35};
+static long long g_seed_us[3]; /* thread-microseconds: bmh_smem_batch, building the look-up keys, bmh_sa_batch */
 static __thread qa_seed_t *qa_seed; /* the batch this thread is chaining, or NULL */
 static __thread int qa_seed_cur;    /* index of the read mem_chain is working on */
 
@@ -124,6 +143,7 @@ static void qa_seed_batch_begin(bmh_ctx_t *ctx, const ref_mem_opt_t *opt, const 
 	bmh_smem_opt_t so;
 	qa_seed_t *S;
 	size_t tot = 0, call_cap, intv_cap, nk = 0, k;
+	double ts[4];
 	int r, rc, i;
 	qa_seed = 0;
 	if (e && e[0] == '0') return;
@@ -138,6 +158,7 @@ static void qa_seed_batch_begin(bmh_ctx_t *ctx, const ref_mem_opt_t *opt, const 
 	S->bwt = bwt, S->n_reads = n, S->reads = reads;
 	S->call_off = (uint32_t *)malloc(4 * ((size_t)n + 1)), S->intv_off = (uint64_t *)malloc(8 * ((size_t)n + 1));
 	/* output arrays sized from the densest batch seen so far in this process (calls / intervals per base) */
+	ts[0] = realtime();
 	for (call_cap = (size_t)(g_seed_density[0] * 1.3 * (double)tot) + 4 * (size_t)n + 64,
 	    intv_cap = (size_t)(g_seed_density[1] * 1.3 * (double)tot) + 1024;;
 	     call_cap *= 2, intv_cap *= 2) {
@@ -148,6 +169,7 @@ static void qa_seed_batch_begin(bmh_ctx_t *ctx, const ref_mem_opt_t *opt, const 
 		free(S->calls), free(S->intv);
 	}
 	if (rc) bmh_tls_die(bmh_last_error(ctx), rc);
+	ts[1] = realtime();
 	if (tot) { /* (a benign race: statistics that only size buffers) */
 		const double dc = (double)S->call_off[n] / (double)tot, di = (double)S->intv_off[n] / (double)tot;
 		if (dc > g_seed_density[0]) g_seed_density[0] = dc;
@@ -171,7 +193,11 @@ static void qa_seed_batch_begin(bmh_ctx_t *ctx, const ref_mem_opt_t *opt, const 
 	qsort(S->sa_k, nk, 8, cmp_u64);
 	for (k = 0, S->n_sa = 0; k < nk; ++k) /* unique */
 		if (S->n_sa == 0 || S->sa_k[S->n_sa - 1] != S->sa_k[k]) S->sa_k[S->n_sa++] = S->sa_k[k];
+	ts[2] = realtime();
 	if ((rc = bmh_sa_batch(ctx, S->sa_k, (int64_t)S->n_sa, S->sa_pos))) bmh_tls_die(bmh_last_error(ctx), rc);
+	ts[3] = realtime();
+	__sync_fetch_and_add(&g_seed_us[0], (long long)((ts[1] - ts[0]) * 1e6)), __sync_fetch_and_add(&g_seed_us[1], (long long)((ts[2] - ts[1]) * 1e6));
+	__sync_fetch_and_add(&g_seed_us[2], (long long)((ts[3] - ts[2]) * 1e6));
 	qa_seed = S;
 }
 
@@ -643,6 +669,9 @@ void mem_process_seqs(const ref_mem_opt_t *opt, const void *bwt, const ref_bntse
 	if (pe) kt_for(opt->n_threads, qa_worker2_pe, &w, n >> 1); /* bwamem.c:1319 */
 	else kt_for(opt->n_threads, qa_worker2_se, &w, n);
 	t_[4] = realtime();
+	if (getenv("BMH_VERBOSE"))
+		fprintf(stderr, "[bwamem_hip] seeding batch thread-seconds so far: bmh_smem_batch %.3f, look-up keys %.3f, bmh_sa_batch %.3f\n",
+		        g_seed_us[0] * 1e-6, g_seed_us[1] * 1e-6, g_seed_us[2] * 1e-6);
 	if (getenv("BMH_VERBOSE"))
 		fprintf(stderr, "[bwamem_hip] phase 1 thread-seconds so far: wait %.3f, seeding batch %.3f, chaining on the host %.3f, wait %.3f, extension batch %.3f\n",
 		        g_p1_us[0] * 1e-6, g_p1_us[1] * 1e-6, g_p1_us[2] * 1e-6, g_p1_us[3] * 1e-6, g_p1_us[4] * 1e-6);

@@ -57,3 +57,21 @@ void bmh_pool_put(bmh_ctx_t *ctx)
 		if (g_slots[i].ctx == ctx) g_slots[i].busy = 0;
 	pthread_mutex_unlock(&g_mu);
 }
+
+/* Create `n` idle contexts ahead of use (called from a background thread while the host program is still loading its
+ * index): context creation costs tens of milliseconds each and contends inside the runtime when many threads do it at
+ * once in the middle of the first chunk. */
+void bmh_pool_prewarm(int n)
+{
+	const char *dev = getenv("BMH_DEVICE");
+	int k;
+	for (k = 0; k < n; ++k) {
+		bmh_ctx_t *ctx = 0;
+		slot_t *s = 0;
+		if (bmh_ctx_create(&ctx, dev ? atoi(dev) : 0)) return; /* no GPU: the first real call will say so loudly */
+		pthread_mutex_lock(&g_mu);
+		if (g_n < BMH_POOL_MAX) s = &g_slots[g_n++], s->ctx = ctx, s->have = 0, s->busy = 0;
+		pthread_mutex_unlock(&g_mu);
+		if (!s) { bmh_ctx_destroy(ctx); return; }
+	}
+}

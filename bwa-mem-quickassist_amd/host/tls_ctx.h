@@ -11,5 +11,6 @@
 /* an idle context with `p` installed (device = $BMH_DEVICE, default 0); aborts on failure */
 bmh_ctx_t *bmh_pool_get(const bmh_params_t *p);
 void bmh_pool_put(bmh_ctx_t *ctx);
+void bmh_pool_prewarm(int n);
 void bmh_tls_die(const char *msg, int code);
 #endif

@@ -75,6 +75,7 @@ def run(fa, fq, threads, batch, preload, out, ksw_dropin=True):
         env["LD_PRELOAD"] = load_package().DROPIN_PATH
         env["BMH_KSW_DROPIN"] = "1" if ksw_dropin else "0"
         env["BMH_VERBOSE"] = "1"
+        env["BMH_SMEM_TRACE"] = "1"
     t0 = time.time()
     with open(out, "w") as f:
         p = subprocess.run([reflib.REF_BWA, "mem", "-t", str(threads), "-b", str(batch), fa] + (fq if isinstance(fq, list) else [fq]), stdout=f,
@@ -85,7 +86,7 @@ def run(fa, fq, threads, batch, preload, out, ksw_dropin=True):
         reads += int(m.group(1))
         real += float(m.group(3))
     shim = [l for l in p.stderr.decode().splitlines() if l.startswith("[bwamem_hip]")]
-    return {"reads": reads, "shim": shim[:12], "process_seqs_real_s": real, "reads_per_s": reads / real if real else None, "wall_s": wall}
+    return {"reads": reads, "shim": shim[:6] + shim[-8:], "process_seqs_real_s": real, "reads_per_s": reads / real if real else None, "wall_s": wall}
 
 
 def main():
