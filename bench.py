@@ -9,6 +9,10 @@ the data path; torch.distributed is used only for the barrier a
 max-over-ranks timing.
 
 Prints ONE JSON line (rank 0).  metric = BASELINE.json's "aligned reads/sec".
+
+Beside the contract fields the line carries, at N=1, three secondary measurements of the other kernels on the path and
+around it (each with its own parity check and CPU figure): `global_alignment` (ksw_global2 + traceback),
+`mate_rescue_sw` (ksw_align2) and `seeding_fmindex` (bwt_smem1 / bwt_sa; needs oracle/_ref to build an index).
 """
 import argparse
 import json
