@@ -181,3 +181,20 @@ def test_multi_contig_reference_sam_identical():
     ref_sam = _run(fa, [f1, f2], os.path.join(tmp, "ref_pe.sam"), extra, False)
     dut_sam = _run(fa, [f1, f2], os.path.join(tmp, "dut_pe.sam"), extra, True)
     assert len(ref_sam) >= 1000 and ref_sam == dut_sam
+
+
+@pytest.mark.parametrize("extra", [["-t", "1", "-b", "100000", "-a", "-M"],      # one thread, one batch, all alignments, -M marking
+                                   ["-t", "4", "-b", "77", "-S"],                 # mate rescue switched off in the reference
+                                   ["-t", "3", "-b", "256", "-P", "-T", "45"]])   # no pairing, higher output threshold
+def test_pe_option_matrix_sam_identical(genome, extra):
+    """Option combinations that change WHICH regions reach mem_reg2aln / mem_matesw (reference fastmap.c:56-100):
+    the chunk-wide batches are supersets and the tables must still serve exactly what the reference asks for."""
+    rng, tmp, fa, ref = genome
+    r1, r2 = _sim_reads(rng, ref, 400, 150, True, pair=True, rescue=0.3)
+    s1 = [x[:int(rng.integers(15, 150))] for x in r1[:40]]  # some mates shorter than a seed, some barely longer
+    f1, f2 = os.path.join(tmp, "om_1.fq"), os.path.join(tmp, "om_2.fq")
+    reflib.write_fastq(f1, s1 + r1[40:], "o")
+    reflib.write_fastq(f2, r2, "o")
+    ref_sam = _run(fa, [f1, f2], os.path.join(tmp, "ref_om.sam"), extra, False)
+    dut_sam = _run(fa, [f1, f2], os.path.join(tmp, "dut_om.sam"), extra, True)
+    assert len(ref_sam) >= 800 and ref_sam == dut_sam
