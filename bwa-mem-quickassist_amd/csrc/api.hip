@@ -495,7 +495,7 @@ int bmh_sw_batch_device(bmh_ctx_t *ctx, const uint8_t *d_pool, const bmh_sw_task
 	if (!ctx->have_params) return BMH_E_ARG;
 	if (n > 0xffffffffLL) return BMH_E_ARG;
 	BMH_HIP(ctx, hipSetDevice(ctx->device));
-	return launch_sw(ctx, d_pool, d_tasks, n, d_res, -1, -1);
+	return launch_sw(ctx, d_pool, d_tasks, n, d_res, -1, -1, -1);
 }
 
 int bmh_sw_batch(bmh_ctx_t *ctx, const uint8_t *pool, size_t pool_bytes, const bmh_sw_task_t *tasks, int64_t n,
@@ -510,9 +510,10 @@ int bmh_sw_batch(bmh_ctx_t *ctx, const uint8_t *pool, size_t pool_bytes, const b
 		if (!ctx->pool_resident) return BMH_E_ARG;
 		pool_bytes = ctx->pool_bytes;
 	}
-	int qmax = 1, tmax = 1, rc;
+	int qmax = 1, tmax = 1, qmin = 65535, rc;
 	for (int64_t k = 0; k < n; ++k) {
 		const bmh_sw_task_t &x = tasks[k];
+		qmin = std::min(qmin, (int)x.qlen);
 		const bool qr = x.flags & BMH_F_QREV, tr = x.flags & BMH_F_TREV, tp = x.flags & BMH_F_TPAC;
 		const uint64_t qlo = qr ? x.q_off - (x.qlen ? x.qlen - 1 : 0) : x.q_off;
 		const uint64_t tlo = tr ? x.t_off - (x.tlen ? x.tlen - 1 : 0) : x.t_off;
@@ -542,7 +543,7 @@ int bmh_sw_batch(bmh_ctx_t *ctx, const uint8_t *pool, size_t pool_bytes, const b
 	if (!resident) BMH_HIP(ctx, hipMemcpyAsync(ctx->d_pool.p, pool, pool_bytes, hipMemcpyHostToDevice, ctx->stream));
 	BMH_HIP(ctx, hipMemcpyAsync(ctx->d_tasks.p, tasks, (size_t)n * sizeof(bmh_sw_task_t), hipMemcpyHostToDevice, ctx->stream));
 	if ((rc = launch_sw(ctx, (const uint8_t *)ctx->d_pool.p, (const bmh_sw_task_t *)ctx->d_tasks.p, n,
-	                    (bmh_sw_result_t *)ctx->d_res.p, qmax, tmax)))
+	                    (bmh_sw_result_t *)ctx->d_res.p, qmax, tmax, qmin)))
 		return rc;
 	BMH_HIP(ctx, hipMemcpyAsync(results, ctx->d_res.p, (size_t)n * sizeof(bmh_sw_result_t), hipMemcpyDeviceToHost, ctx->stream));
 	return fetch_err(ctx); // synchronises

@@ -85,7 +85,7 @@ int launch_extend_grp(bmh_ctx *ctx, int nv, const uint8_t *d_pool, const bmh_ext
 int launch_extend_lanex(bmh_ctx *ctx, int lpt, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
                         bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, int min_count);
 int launch_sw(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks, int64_t n, bmh_sw_result_t *d_res,
-              int qcap, int tcap);
+              int qcap, int tcap, int qmin);
 int launch_sw_lane(bmh_ctx *ctx, int b, bool corr, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks, int64_t n,
                    bmh_sw_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, uint16_t *d_rm, int rows_cap,
                    int grid, int pass2, uint32_t *d_next);

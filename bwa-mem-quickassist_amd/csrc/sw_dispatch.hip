@@ -10,12 +10,12 @@ namespace bmh {
 // largest padded query and target length of a device-resident batch (the *_device entry point has no host view)
 __global__ void sw_caps_kernel(const bmh_sw_task_t *__restrict__ tasks, long long n, int *caps)
 {
-	int q = 0, t = 0;
+	int q = 0, t = 0, qi = 0; // qi = 65535 - shortest query
 	for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (long long)gridDim.x * blockDim.x) {
-		q = max(q, (int)tasks[k].qlen), t = max(t, (int)min(tasks[k].tlen, 0x7fffffffu));
+		q = max(q, (int)tasks[k].qlen), t = max(t, (int)min(tasks[k].tlen, 0x7fffffffu)), qi = max(qi, 65535 - (int)tasks[k].qlen);
 	}
-	q = wave_reduce_max(q), t = wave_reduce_max(t);
-	if ((threadIdx.x & 63) == 0) atomicMax(&caps[0], q), atomicMax(&caps[1], t);
+	q = wave_reduce_max(q), t = wave_reduce_max(t), qi = wave_reduce_max(qi);
+	if ((threadIdx.x & 63) == 0) atomicMax(&caps[0], q), atomicMax(&caps[1], t), atomicMax(&caps[2], qi);
 }
 
 // ---- device-side routing: a counting sort by (kernel, query length, target length), like the extension dispatcher
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(kSwSortThreads) void sw_hist_kernel(const bmh_sw_ta
                                                                  const bmh_sw_result_t *__restrict__ res, DevParams P,
                                                                  uint32_t *__restrict__ hist,
                                                                  uint16_t *__restrict__ binkey, int mode, int pass2,
-                                                                 const uint8_t *__restrict__ pool)
+                                                                 const uint8_t *__restrict__ pool, int qfine)
 {
 	__shared__ uint32_t lh[kExtBins * kSortKeysHost];
 	for (int t = threadIdx.x; t < kExtBins * kSortKeysHost; t += kSwSortThreads) lh[t] = 0;
@@ -62,7 +62,9 @@ __global__ __launch_bounds__(kSwSortThreads) void sw_hist_kernel(const bmh_sw_ta
 			rows = min(rows, 2 * qlen + 16); // the reversed pass stops once the score is reached
 		}
 		// lanes of a wave must share ceil(qlen/16) and should share qlen (uniform padding) and the row count
-		const int key = bin >= 2 ? 0 : (min(qlen, 255) << 3) | min(rows >> 7, 7);
+		// qfine >= 0: all queries of the batch lie in [qfine, qfine+64) (the usual case: one read length) -- six bits tell them
+		// apart and five are left for the row count, so that the lanes of a wave finish within 32 rows of one another
+		const int key = bin >= 2 ? 0 : (!pass2 && qfine >= 0) ? ((qlen - qfine) << 5) | min(rows >> 5, 31) : (min(qlen, 255) << 3) | min(rows >> 7, 7);
 		if (bin < 2 && has_n) bin += 3;
 		const int bk = bin * kSortKeysHost + key;
 		binkey[k] = (uint16_t)bk;
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(kSwSortThreads) void sw_hist_kernel(const bmh_sw_ta
 }
 
 int launch_sw(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks, int64_t n, bmh_sw_result_t *d_res,
-              int qcap, int tcap)
+              int qcap, int tcap, int qmin)
 {
 	if (n <= 0) return BMH_OK;
 	if (ctx->params.o_ins < 1) {
@@ -88,14 +90,15 @@ int launch_sw(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks,
 	int rc;
 	if (qcap < 0 || tcap < 0) { // one small reduction + read-back
 		if ((rc = ensure(ctx, ctx->d_scratch, 256))) return rc;
-		int *caps = (int *)ctx->d_scratch.p, h[2] = {0, 0};
-		BMH_HIP(ctx, hipMemsetAsync(caps, 0, 8, ctx->stream));
+		int *caps = (int *)ctx->d_scratch.p, h[3] = {0, 0, 0};
+		BMH_HIP(ctx, hipMemsetAsync(caps, 0, 12, ctx->stream));
 		hipLaunchKernelGGL(sw_caps_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 1024)), dim3(256), 0,
 		                   ctx->stream, d_tasks, (long long)n, caps);
-		BMH_HIP(ctx, hipMemcpyAsync(h, caps, 8, hipMemcpyDeviceToHost, ctx->stream));
+		BMH_HIP(ctx, hipMemcpyAsync(h, caps, 12, hipMemcpyDeviceToHost, ctx->stream));
 		BMH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-		qcap = h[0], tcap = h[1];
+		qcap = h[0], tcap = h[1], qmin = 65535 - h[2];
 	}
+	const int qfine = (qmin >= 1 && qcap - qmin < 64) ? qmin : -1; // see sw_hist_kernel
 	qcap = std::max(qcap, 1) + 16, tcap = std::max(tcap, 1);
 	if (ctx->params.o_del > 255 || ctx->params.e_del > 255 || ctx->params.o_ins > 255 || ctx->params.e_ins > 255) {
 		ctx->last_error = "the Smith-Waterman kernels need gap penalties below 256";
@@ -115,7 +118,7 @@ int launch_sw(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks,
 		uint32_t *hist = counts + 16;
 		uint16_t *binkey = (uint16_t *)(hist + (size_t)kExtBins * kSortKeysHost);
 		hipLaunchKernelGGL(sw_hist_kernel, dim3((unsigned)cg), dim3(kSwSortThreads), 0, ctx->stream, d_tasks, (long long)n,
-		                   d_res, ctx->dev, hist, binkey, mode, pass2, d_pool);
+		                   d_res, ctx->dev, hist, binkey, mode, pass2, d_pool, qfine);
 		if ((rc = sort_tasks_finish(ctx, n, nullptr, (unsigned)cg))) return rc;
 		if ((rc = launch_sw_lane(ctx, 80, false, d_pool, d_tasks, n, d_res, lists + N, counts + 1, d_rm, tcap, grid, pass2, counts + 9))) return rc;
 		if ((rc = launch_sw_lane(ctx, 80, true, d_pool, d_tasks, n, d_res, lists + 4 * N, counts + 4, d_rm, tcap, grid, pass2, counts + 12))) return rc;
