@@ -57,6 +57,18 @@ __attribute__((constructor)) static void qa_shim_loaded(void)
 	pthread_t t;
 	if (e && e[0] == '0') return;
 	if (!pl || !strstr(pl, "libbwamem_hip_dropin")) return; /* only when preloaded into a host program, not when merely dlopen()ed */
+	{ /* ... and only into `<prog> mem ...`: index building, usage errors etc. never touch the GPU */
+		char buf[512];
+		FILE *f = fopen("/proc/self/cmdline", "rb");
+		size_t n = f ? fread(buf, 1, sizeof(buf) - 1, f) : 0, i, first_len;
+		int is_mem = 0;
+		if (f) fclose(f);
+		buf[n] = 0;
+		first_len = strlen(buf);
+		for (i = first_len + 1; i < n; i += strlen(buf + i) + 1)
+			if (!strcmp(buf + i, "mem")) { is_mem = 1; break; }
+		if (!is_mem) return;
+	}
 	if (pthread_create(&t, 0, prewarm_thread, 0) == 0) pthread_detach(t);
 }
 
