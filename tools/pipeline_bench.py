@@ -97,11 +97,15 @@ def main():
     ap.add_argument("--batch", type=int, default=8192)
     ap.add_argument("--pe", action="store_true", help="paired-end reads; the DUT then also batches mate rescue on the GPU")
     ap.add_argument("--noisy", type=float, default=0.3, help="--pe: fraction of second mates that need rescue")
+    ap.add_argument("--repeats", type=int, default=0, help="plant this many diverged repeats (200-3000 bp) in the genome")
     ap.add_argument("--full", action="store_true", help="also time the per-call ksw_global2 GPU drop-in (slow by design)")
     a = ap.parse_args()
     rng = np.random.default_rng(20261007)
     tmp = tempfile.mkdtemp(prefix="bmh_pipe_")
     ref = kswgen.rand_seq(rng, a.genome)
+    for _ in range(a.repeats):  # multi-copy sequence: seeds with many occurrences, secondary hits, mapQ ties, more rescue
+        src, dst, L = int(rng.integers(0, a.genome - 4000)), int(rng.integers(0, a.genome - 4000)), int(rng.integers(200, 3000))
+        ref[dst:dst + L] = kswgen.mutate(rng, ref[src:src + L + 40], float(rng.choice([0.0, 0.005, 0.02])), 0.001, 0.001, 2)[:L]
     fa, fq = os.path.join(tmp, "ref.fa"), os.path.join(tmp, "reads.fq")
     reflib.write_fasta(fa, "synth", ref)
     t0 = time.time()
@@ -116,7 +120,7 @@ def main():
     else:
         reads = sim_reads_fast(rng, ref, a.reads, 150)
         reflib.write_fastq(fq, list(reads))
-    res = {"genome_bp": a.genome, "reads": a.reads, "paired": bool(a.pe), "index_s": t_index, "runs": []}
+    res = {"genome_bp": a.genome, "repeats": a.repeats, "reads": a.reads, "paired": bool(a.pe), "index_s": t_index, "runs": []}
     for t in [int(x) for x in a.threads.split(",")]:
         r = run(fa, fq, t, a.batch, False, os.path.join(tmp, "ref.sam"))
         refsam = [l for l in open(os.path.join(tmp, "ref.sam")) if not l.startswith("@PG")]
