@@ -22,6 +22,8 @@
 const bmh_params_t *bmh_ctx_params_(const bmh_ctx_t *ctx);
 int bmh_upload_pool(bmh_ctx_t *ctx, const uint8_t *pool, size_t bytes);
 
+enum { SMALL_CAP = 24 }; /* CIGAR slots reserved per task on the first attempt of a try */
+
 static void put_num(char *s, size_t *l, int c) /* kputw, kstring.h:62-77, c >= 0 */
 {
 	char buf[16];
@@ -178,21 +180,44 @@ int bmh_reg2cigar_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, const
 				min_w = abs(c->tl - c->ql) + 3;
 				w = w > min_w ? w : min_w;
 				t->q_off = c->q_off, t->t_off = c->t_off, t->qlen = (uint16_t)c->ql, t->tlen = (uint16_t)c->tl, t->w = w;
-				t->cigar_off = (uint32_t)slot, t->cigar_cap = (uint32_t)(c->ql + c->tl + 2);
+				/* a CIGAR can have ql+tl+1 operations but almost never has more than a few: reserve SMALL_CAP slots, so that the
+				 * words coming back over PCIe are not 99 % padding, and redo the rare task that needs more (below) */
+				t->cigar_off = (uint32_t)slot, t->cigar_cap = (uint32_t)(c->ql + c->tl + 2 < SMALL_CAP ? c->ql + c->tl + 2 : SMALL_CAP);
 				slot += t->cigar_cap;
 				owner[n_active++] = k;
 			}
 		}
 		if (n_active > 0) {
+			int64_t n_big = 0;
 			if (round == 0) { if ((rc = bmh_upload_pool(ctx, pool, pool_bytes + 16))) goto done; }
-			if ((rc = bmh_global_batch(ctx, 0, 0, tasks, n_active, gres, scratch, scratch_words + 4))) goto done;
-			for (k = 0; k < n_active; ++k) cg[owner[k]].score = gres[k].score, cg[owner[k]].n_cigar = gres[k].n_cigar;
+			rc = bmh_global_batch(ctx, 0, 0, tasks, n_active, gres, scratch, slot + 4);
+			if (rc && rc != BMH_E_CIGAR_CAP) goto done;
+			for (k = 0; k < n_active; ++k) {
+				cg_t *c = &cg[owner[k]];
+				c->score = gres[k].score, c->n_cigar = gres[k].n_cigar;
+				if ((uint32_t)c->n_cigar <= tasks[k].cigar_cap) memcpy(final_cig + c->fslot, scratch + c->slot, 4 * (size_t)c->n_cigar);
+				else tasks[n_big] = tasks[k], owner[n_big] = owner[k], ++n_big; /* (n_big <= k: in-place compaction) */
+			}
+			if (n_big > 0) { /* the few long CIGARs again, with the full ql+tl+2 slots */
+				slot = 0;
+				for (k = 0; k < n_big; ++k) {
+					cg_t *c = &cg[owner[k]];
+					tasks[k].cigar_off = (uint32_t)slot, tasks[k].cigar_cap = (uint32_t)(c->ql + c->tl + 2), c->slot = (uint32_t)slot;
+					slot += tasks[k].cigar_cap;
+				}
+				if ((rc = bmh_global_batch(ctx, 0, 0, tasks, n_big, gres, scratch, slot + 4))) goto done;
+				for (k = 0; k < n_big; ++k) {
+					cg_t *c = &cg[owner[k]];
+					c->score = gres[k].score, c->n_cigar = gres[k].n_cigar;
+					memcpy(final_cig + c->fslot, scratch + c->slot, 4 * (size_t)c->n_cigar);
+				}
+			}
+			rc = BMH_OK;
 		}
 		n_active = 0;
 		for (k = 0; k < n_req; ++k) { /* keep this try's CIGAR, decide about the next one */
 			cg_t *c = &cg[k];
 			if (!c->active) continue;
-			if (!c->nodp) memcpy(final_cig + c->fslot, scratch + c->slot, 4 * (size_t)c->n_cigar);
 			if (c->score == c->last_sc) c->active = 0; /* bwamem.c:1198 */
 			else {
 				c->last_sc = c->score, c->w2 <<= 1;

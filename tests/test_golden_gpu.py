@@ -75,3 +75,54 @@ def test_hip_reg2cigar_driver_matches_reference_fixture(ctx):
                 assert int(r["score"]) == oscore and int(r["tries"]) == otries
             n += 1
     assert n >= 2000
+
+
+def test_hip_reg2cigar_long_cigars_take_the_retry_path(ctx):
+    """The driver reserves few CIGAR slots per task and redoes a task whose CIGAR needs more: reads with an indel every
+    ~25 bases (50+ operations), both strands, mixed with ordinary ones, against the oracle."""
+    rng = np.random.default_rng(201)
+    l_pac = 20000
+    bases = rng.integers(0, 4, l_pac, dtype=np.uint8)
+    pad = np.concatenate([bases, np.zeros(4, np.uint8)])
+    q4 = pad[: (len(pad) // 4) * 4].reshape(-1, 4)
+    pac = (q4[:, 0] << 6 | q4[:, 1] << 4 | q4[:, 2] << 2 | q4[:, 3]).astype(np.uint8)
+    p = kswlib.make_params()
+    ctx.set_params(p)
+    reads, reqs = [], []
+    for k in range(60):
+        L = int(rng.integers(300, 640))
+        pos = int(rng.integers(0, l_pac - L - 50))
+        src = bases[pos:pos + L + 40]
+        out, i, since = [], 0, 0
+        step = 25 if k % 3 else 400  # every third read is an ordinary one
+        while len(out) < L and i < len(src):
+            since += 1
+            if since >= step:
+                since = 0
+                if rng.random() < 0.5:
+                    i += 1  # deletion from the read
+                else:
+                    out.append(int(rng.integers(0, 4)))  # insertion
+                    continue
+            out.append(int(src[i]))
+            i += 1
+        rd = np.array(out[:L], dtype=np.uint8)
+        rb, re = pos, pos + i
+        rq = np.zeros((), kswlib.CIGAR_REQ)
+        if k % 2:  # reverse strand: the read is the reverse complement, the region lies in [l_pac, 2*l_pac)
+            rd = (3 - rd[::-1]).astype(np.uint8)
+            rb, re = 2 * l_pac - re, 2 * l_pac - rb
+        rq["read"], rq["qb"], rq["qe"], rq["rb"], rq["re"], rq["truesc"], rq["reg_w"] = len(reads), 0, len(rd), rb, re, len(rd) - 60, 100
+        reads.append(rd), reqs.append(rq)
+    reqs = np.array(reqs)
+    res, cig, md = ctx.reg2cigar_batch(l_pac, pac, reads, reqs)
+    mdb = bytes(md)
+    long_ones = 0
+    for rq, r in zip(reqs, res):
+        oscore, owords, onm, omd, otries = kswlib.orc_reg2cigar(p, l_pac, pac, reads[int(rq["read"])], rq)
+        words = cig[int(r["cigar_off"]): int(r["cigar_off"]) + int(r["n_cigar"])]
+        assert int(r["score"]) == oscore and int(r["tries"]) == otries and int(r["NM"]) == onm
+        assert np.array_equal(words, owords)
+        assert mdb[int(r["md_off"]): int(r["md_off"]) + int(r["md_len"])] == omd.rstrip(b"\0")
+        long_ones += len(owords) > 24
+    assert long_ones >= 30
