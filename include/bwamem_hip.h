@@ -351,6 +351,20 @@ typedef struct bmh_smem_call { /* one bwt_smem1 call and where its result interv
 	uint32_t rsv;
 } bmh_smem_call_t;
 
+/* The index files of `bwa index` (<prefix>.bwt/.sa/.ann/.pac; reference bwt.c:380-421, bntseq.c:94-140, bwa.c:291)
+ * read into plain arrays: what bmh_ctx_set_bwt / bmh_ctx_set_pac take.  Host I/O only, no GPU involved. */
+typedef struct bmh_index {
+	bmh_bwt_t bwt;    /* arrays owned by the index */
+	int64_t l_pac;
+	uint8_t *pac;     /* l_pac/4+1 bytes */
+	int32_t n_seqs;   /* reference sequences (.ann): name, offset in the concatenation, length */
+	char **names;
+	int64_t *offsets;
+	int32_t *lens;
+} bmh_index_t;
+int bmh_index_load(const char *prefix, bmh_index_t **out); /* BMH_E_ARG if a file is missing or inconsistent */
+void bmh_index_free(bmh_index_t *ix);
+
 /* Make the index resident on the context's device (one copy per device and host array, shared by all contexts). */
 int bmh_ctx_set_bwt(bmh_ctx_t *ctx, const bmh_bwt_t *bwt);
 /* For every read: the bwt_smem1 calls of smem_next2's iteration, in order.  Read r's calls are
