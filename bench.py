@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--reads", type=int, default=1_000_000, help="simulated reads per GPU per step")
-    ap.add_argument("--workload", default="150bp", choices=["150bp", "mixed100-300"])
+    ap.add_argument("--workload", default="150bp", choices=["150bp", "250bp", "mixed100-300"])
     ap.add_argument("--sw-tasks", type=int, default=400_000,
                     help="mate-rescue Smith-Waterman tasks for the secondary measurement (0 = skip)")
     ap.add_argument("--seed-reads", type=int, default=200_000,
@@ -207,7 +207,11 @@ def main():
         ql, tl = stasks["qlen"].astype(np.int64), stasks["tlen"].astype(np.int64)
         second = sres["tb"] >= 0
         cells = float((ql * tl).sum() + ((sres["qe"].astype(np.int64) + 1) * (sres["te"] - sres["tb"] + 1))[second].sum())
-        swb = {"kernel": "sw_lane_kernel<80> (ksw_align2 byte mode, 64 tasks/wave, packed u16)", "tasks": int(len(stasks)),
+        sw_word = bool((stasks["xtra"] & 0x10000).sum() * 2 < len(stasks))  # KSW_XBYTE absent: ksw_i16's layout
+        sw_cols = int(stasks["qlen"].max())
+        swb = {"kernel": "sw_lane_kernel<%d%s> (ksw_align2 %s mode, 64 tasks/wave, packed u16)"
+                         % (128 if sw_word or sw_cols > 160 else 80 if sw_cols > 80 else 40, ", WORD" if sw_word else "",
+                            "word" if sw_word else "byte"), "tasks": int(len(stasks)),
                "ms": s_ms, "tasks_per_s": len(stasks) / (s_ms * 1e-3), "gcups": cells / (s_ms * 1e-3) / 1e9,
                "mean_qlen": float(ql.mean()), "mean_tlen": float(tl.mean()), "rescued": float(second.mean()),
                "parity": "bit-exact vs oracle (kswr_t, %d sampled tasks)" % ns if ok else "MISMATCH vs oracle"}

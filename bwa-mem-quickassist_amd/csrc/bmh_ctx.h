@@ -79,6 +79,7 @@ int launch_global_lane(bmh_ctx *ctx, int c, const uint8_t *d_pool, const bmh_glb
                        bmh_glb_result_t *d_res, uint32_t *d_cigar, const uint32_t *d_order, const uint32_t *d_count,
                        int rows_cap);
 constexpr int kExtBins = 6;        // length bins of the extension dispatcher
+constexpr int kSortBins = 8;       // bins the shared counting sort can tell apart (extension 6, global 6, Smith-Waterman 8)
 constexpr int kGrpTcapHost = 1024; // == kGrpTcap in extend_grp.hip
 int launch_extend_grp(bmh_ctx *ctx, int nv, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
                       bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count);
@@ -86,7 +87,7 @@ int launch_extend_lanex(bmh_ctx *ctx, int lpt, const uint8_t *d_pool, const bmh_
                         bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, int min_count);
 int launch_sw(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks, int64_t n, bmh_sw_result_t *d_res,
               int qcap, int tcap, int qmin);
-int launch_sw_lane(bmh_ctx *ctx, int b, bool corr, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks, int64_t n,
+int launch_sw_lane(bmh_ctx *ctx, int b, bool corr, bool word, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks, int64_t n,
                    bmh_sw_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, uint16_t *d_rm, int rows_cap,
                    int grid, int pass2, uint32_t *d_next);
 int launch_sw_generic(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks, int64_t n,

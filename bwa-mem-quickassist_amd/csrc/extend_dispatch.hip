@@ -53,8 +53,8 @@ __global__ __launch_bounds__(kSortThreads) void sort_hist_kernel(const bmh_ext_t
                                                                  uint32_t *__restrict__ hist,
                                                                  uint16_t *__restrict__ binkey, int mode)
 {
-	__shared__ uint32_t lh[kExtBins * kSortKeys];
-	for (int t = threadIdx.x; t < kExtBins * kSortKeys; t += kSortThreads) lh[t] = 0;
+	__shared__ uint32_t lh[kSortBins * kSortKeys];
+	for (int t = threadIdx.x; t < kSortBins * kSortKeys; t += kSortThreads) lh[t] = 0;
 	__syncthreads();
 	const long long chunk = (n + gridDim.x - 1) / gridDim.x, lo = chunk * blockIdx.x, hi = min(lo + chunk, n);
 	for (long long k = lo + threadIdx.x; k < hi; k += kSortThreads) {
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_hist_kernel(const bmh_ext_t
 		atomicAdd(&lh[bk], 1u);
 	}
 	__syncthreads();
-	for (int t = threadIdx.x; t < kExtBins * kSortKeys; t += kSortThreads)
+	for (int t = threadIdx.x; t < kSortBins * kSortKeys; t += kSortThreads)
 		if (lh[t]) atomicAdd(&hist[t], lh[t]);
 }
 
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(1024) void sort_scan_kernel(uint32_t *__restrict__ 
 	static_assert(kSortKeys == 2048, "two keys per thread");
 	__shared__ uint32_t part[1024];
 	const int t = threadIdx.x;
-	for (int b = 0; b < kExtBins; ++b) {
+	for (int b = 0; b < kSortBins; ++b) {
 		const uint32_t v0 = hist[b * kSortKeys + 2 * t], v1 = hist[b * kSortKeys + 2 * t + 1];
 		part[t] = v0 + v1;
 		__syncthreads();
@@ -101,13 +101,13 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint32
                                                                     const uint16_t *__restrict__ binkey,
                                                                     uint32_t *__restrict__ lists)
 {
-	__shared__ uint32_t lh[kExtBins * kSortKeys];
-	for (int t = threadIdx.x; t < kExtBins * kSortKeys; t += kSortThreads) lh[t] = 0;
+	__shared__ uint32_t lh[kSortBins * kSortKeys];
+	for (int t = threadIdx.x; t < kSortBins * kSortKeys; t += kSortThreads) lh[t] = 0;
 	__syncthreads();
 	const long long chunk = (n + gridDim.x - 1) / gridDim.x, lo = chunk * blockIdx.x, hi = min(lo + chunk, n);
 	for (long long k = lo + threadIdx.x; k < hi; k += kSortThreads) atomicAdd(&lh[binkey[k]], 1u);
 	__syncthreads();
-	for (int t = threadIdx.x; t < kExtBins * kSortKeys; t += kSortThreads)
+	for (int t = threadIdx.x; t < kSortBins * kSortKeys; t += kSortThreads)
 		if (lh[t]) lh[t] = atomicAdd(&cursor[t], lh[t]); // count -> start of this block's range
 	__syncthreads();
 	for (long long k = lo + threadIdx.x; k < hi; k += kSortThreads) {
@@ -121,8 +121,8 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint32
 static_assert(kSortKeys == kSortKeysHost, "keep bmh_ctx.h in sync");
 int sort_tasks_begin(bmh_ctx *ctx, int64_t n, uint32_t **counts, uint32_t **lists)
 {
-	const size_t N = (size_t)n, hist_words = (size_t)kExtBins * kSortKeys;
-	int rc = ensure(ctx, ctx->d_bins, (16 + hist_words + (N + 1) / 2 + 1 + (size_t)kExtBins * N) * 4);
+	const size_t N = (size_t)n, hist_words = (size_t)kSortBins * kSortKeys;
+	int rc = ensure(ctx, ctx->d_bins, (16 + hist_words + (N + 1) / 2 + 1 + (size_t)kSortBins * N) * 4);
 	if (rc) return rc;
 	*counts = (uint32_t *)ctx->d_bins.p;
 	*lists = *counts + 16 + hist_words + (N + 1) / 2 + 1;
@@ -132,7 +132,7 @@ int sort_tasks_begin(bmh_ctx *ctx, int64_t n, uint32_t **counts, uint32_t **list
 
 int sort_tasks_finish(bmh_ctx *ctx, int64_t n, const uint32_t *d_order, unsigned blocks)
 {
-	const size_t N = (size_t)n, hist_words = (size_t)kExtBins * kSortKeys;
+	const size_t N = (size_t)n, hist_words = (size_t)kSortBins * kSortKeys;
 	uint32_t *counts = (uint32_t *)ctx->d_bins.p, *hist = counts + 16;
 	uint16_t *binkey = (uint16_t *)(hist + hist_words);
 	uint32_t *lists = hist + hist_words + (N + 1) / 2 + 1;
@@ -153,7 +153,7 @@ int launch_extend(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_t
 	uint32_t *counts, *lists;
 	if ((rc = sort_tasks_begin(ctx, n, &counts, &lists))) return rc;
 	uint32_t *hist = counts + 16;
-	uint16_t *binkey = (uint16_t *)(hist + (size_t)kExtBins * kSortKeys);
+	uint16_t *binkey = (uint16_t *)(hist + (size_t)kSortBins * kSortKeys);
 	long long cg = (n + 1023) / 1024;
 	if (cg > kSortBlocks) cg = kSortBlocks;
 	hipLaunchKernelGGL(sort_hist_kernel, dim3((unsigned)cg), dim3(kSortThreads), 0, ctx->stream, d_tasks, d_order, (long long)n,

@@ -39,45 +39,52 @@ __device__ __forceinline__ int fm_count(uint32_t w, uint32_t pat, uint32_t keep)
 	return __popc(~(x | x >> 1) & 0x55555555u & keep);
 }
 
+// Four counts / candidates as NAMED members, picked by a select chain: a per-lane index into an array would send the
+// whole array through scratch memory on every extension (it did: 128 bytes written and re-read per bwt_extend).
+struct U4 {
+	uint64_t a, b, c, d;
+};
+__device__ __forceinline__ uint64_t pick(const U4 &v, int i) { return i == 0 ? v.a : i == 1 ? v.b : i == 2 ? v.c : v.d; }
+
 // bwt_occ4, bwt.c:159-177
-__device__ __forceinline__ void fm_occ4(const DevBwt &B, uint64_t k, uint64_t cnt[4])
+__device__ __forceinline__ U4 fm_occ4(const DevBwt &B, uint64_t k)
 {
-	if (k == (uint64_t)-1) { cnt[0] = cnt[1] = cnt[2] = cnt[3] = 0; return; }
+	U4 r{0, 0, 0, 0};
+	if (k == (uint64_t)-1) return r;
 	k -= (k >= B.primary); // the sentinel is not stored
 	const uint4 *blk = (const uint4 *)(B.bwt + ((k >> 7) << 4));
 	const uint4 c0 = blk[0], c1 = blk[1], w0 = blk[2], w1 = blk[3];
-	cnt[0] = (uint64_t)c0.y << 32 | c0.x, cnt[1] = (uint64_t)c0.w << 32 | c0.z;
-	cnt[2] = (uint64_t)c1.y << 32 | c1.x, cnt[3] = (uint64_t)c1.w << 32 | c1.z;
 	const uint32_t w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 	const int full = (int)((k & 127) >> 4), rest = (int)(k & 15) + 1;
-	int n[4] = {0, 0, 0, 0};
+	int n0 = 0, n1 = 0, n2 = 0, n3 = 0;
 #pragma unroll
 	for (int j = 0; j < 8; ++j) {
 		const uint32_t keep = j < full ? 0xffffffffu : j == full ? 0xffffffffu << (32 - 2 * rest) : 0u;
-#pragma unroll
-		for (int c = 0; c < 4; ++c) n[c] += fm_count(w[j], (uint32_t)c * 0x55555555u, keep);
+		n0 += fm_count(w[j], 0x00000000u, keep), n1 += fm_count(w[j], 0x55555555u, keep);
+		n2 += fm_count(w[j], 0xaaaaaaaau, keep), n3 += fm_count(w[j], 0xffffffffu, keep);
 	}
-#pragma unroll
-	for (int c = 0; c < 4; ++c) cnt[c] += (uint64_t)n[c];
+	r.a = ((uint64_t)c0.y << 32 | c0.x) + (uint64_t)n0, r.b = ((uint64_t)c0.w << 32 | c0.z) + (uint64_t)n1;
+	r.c = ((uint64_t)c1.y << 32 | c1.x) + (uint64_t)n2, r.d = ((uint64_t)c1.w << 32 | c1.z) + (uint64_t)n3;
+	return r;
 }
 
-// bwt_extend, bwt.c:261-274
-__device__ __forceinline__ void fm_extend(const DevBwt &B, const Intv &ik, Intv ok[4], bool is_back)
+// bwt_extend, bwt.c:261-274, for ONE base c (the only one of the four the caller goes on with)
+__device__ __forceinline__ Intv fm_extend(const DevBwt &B, const Intv &ik, int c, bool is_back)
 {
-	uint64_t tk[4], tl[4];
 	const uint64_t a = is_back ? ik.x0 : ik.x1, b = is_back ? ik.x1 : ik.x0; // a = x[!is_back], b = x[is_back]
-	fm_occ4(B, a - 1, tk);
-	fm_occ4(B, a - 1 + ik.x2, tl);
-	uint64_t na[4], nb[4];
-#pragma unroll
-	for (int i = 0; i < 4; ++i) na[i] = B.L2[i] + 1 + tk[i], ok[i].x2 = tl[i] - tk[i];
-	nb[3] = b + (a <= B.primary && a + ik.x2 - 1 >= B.primary);
-	nb[2] = nb[3] + ok[3].x2, nb[1] = nb[2] + ok[2].x2, nb[0] = nb[1] + ok[1].x2;
-#pragma unroll
-	for (int i = 0; i < 4; ++i) {
-		ok[i].x0 = is_back ? na[i] : nb[i];
-		ok[i].x1 = is_back ? nb[i] : na[i];
-	}
+	const U4 tk = fm_occ4(B, a - 1), tl = fm_occ4(B, a - 1 + ik.x2);
+	const U4 sz{tl.a - tk.a, tl.b - tk.b, tl.c - tk.c, tl.d - tk.d}; // ok[i].x[2]
+	const U4 l2{B.L2[0], B.L2[1], B.L2[2], B.L2[3]};
+	// ok[3].x[is_back] = b + [the sentinel lies in the interval]; ok[i].x[is_back] = ok[i+1].x[is_back] + ok[i+1].x[2]
+	const uint64_t n3 = b + (a <= B.primary && a + ik.x2 - 1 >= B.primary), n2 = n3 + sz.d, n1 = n2 + sz.c, n0 = n1 + sz.b;
+	const U4 nb{n0, n1, n2, n3};
+	const uint64_t na = pick(l2, c) + 1 + pick(tk, c);
+	Intv o;
+	o.x2 = pick(sz, c);
+	o.x0 = is_back ? na : pick(nb, c);
+	o.x1 = is_back ? pick(nb, c) : na;
+	o.info = 0;
+	return o;
 }
 
 // a lane's three interval stacks live in a slab laid out [entry][lane]: lanes of a wave walking their stacks in step
@@ -94,17 +101,16 @@ __device__ int fm_smem1(const DevBwt &B, int len, const uint8_t *q, int x, int m
 	*n_mem = 0;
 	if (q[x] > 3) return x + 1;
 	if (min_intv < 1) min_intv = 1;
-	Intv ik, ok[4];
+	Intv ik;
 	int np, nc = 0, nm = 0, i;
 	{
 		const int c = q[x];
-		ik.x0 = B.L2[c] + 1, ik.x2 = B.L2[c + 1] - B.L2[c], ik.x1 = B.L2[3 - c] + 1, ik.info = (uint64_t)x + 1; // bwt_set_intv
+		const U4 l2{B.L2[0], B.L2[1], B.L2[2], B.L2[3]}, l2n{B.L2[1], B.L2[2], B.L2[3], B.L2[4]};
+		ik.x0 = pick(l2, c) + 1, ik.x2 = pick(l2n, c) - pick(l2, c), ik.x1 = pick(l2, 3 - c) + 1, ik.info = (uint64_t)x + 1; // bwt_set_intv
 	}
 	for (i = x + 1; i < len; ++i) { // forward search
 		if (q[i] < 4) {
-			const int c = 3 - q[i];
-			fm_extend(B, ik, ok, false);
-			const Intv o = c == 0 ? ok[0] : c == 1 ? ok[1] : c == 2 ? ok[2] : ok[3];
+			const Intv o = fm_extend(B, ik, 3 - q[i], false);
 			if (o.x2 != ik.x2) {
 				curr[nc++] = ik;
 				if (o.x2 < (uint64_t)min_intv) break;
@@ -133,8 +139,7 @@ __device__ int fm_smem1(const DevBwt &B, int len, const uint8_t *q, int x, int m
 			bool keep = c < 0; // the start of the read or an ambiguous base ends every interval: no extension needed
 			Intv o{};
 			if (!keep) {
-				fm_extend(B, p, ok, true);
-				o = c == 0 ? ok[0] : c == 1 ? ok[1] : c == 2 ? ok[2] : ok[3];
+				o = fm_extend(B, p, c, true);
 				keep = o.x2 < (uint64_t)min_intv;
 			}
 			if (keep) {
@@ -228,15 +233,10 @@ __global__ void sa_kernel(DevBwt B, const uint64_t *__restrict__ ks, long long n
 			const uint64_t x = k - (k > B.primary);
 			const int c = (int)(B.bwt[((x >> 7) << 4) + 8 + ((x & 127) >> 4)] >> ((~x & 15) << 1) & 3); // bwt_B0, bwt.h:70
 			++sa;
-			if (k == B.primary) k = 0; // bwt_invPsi, bwt.c:57
-			else {
-				uint64_t cnt[4];
-				if (k == B.seq_len) k = B.L2[c] + (B.L2[c + 1] - B.L2[c]); // bwt_occ's first special case, bwt.c:112
-				else {
-					fm_occ4(B, k, cnt);
-					k = B.L2[c] + (c == 0 ? cnt[0] : c == 1 ? cnt[1] : c == 2 ? cnt[2] : cnt[3]);
-				}
-			}
+			const U4 l2{B.L2[0], B.L2[1], B.L2[2], B.L2[3]}, l2n{B.L2[1], B.L2[2], B.L2[3], B.L2[4]};
+			if (k == B.primary) k = 0;                // bwt_invPsi, bwt.c:57
+			else if (k == B.seq_len) k = pick(l2n, c); // bwt_occ's first special case, bwt.c:112: L2[c] + (L2[c+1] - L2[c])
+			else k = pick(l2, c) + pick(fm_occ4(B, k), c);
 		}
 		pos[t] = sa + B.sa[k >> B.sa_shift];
 	}

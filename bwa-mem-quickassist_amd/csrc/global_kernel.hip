@@ -217,8 +217,8 @@ __global__ __launch_bounds__(256) void glb_sort_hist_kernel(const bmh_glb_task_t
                                                             uint32_t *__restrict__ hist, uint16_t *__restrict__ binkey,
                                                             DevParams P, int lane_ok, int rows_cap)
 {
-	__shared__ uint32_t lh[kExtBins * kSortKeysHost];
-	for (int t = threadIdx.x; t < kExtBins * kSortKeysHost; t += 256) lh[t] = 0;
+	__shared__ uint32_t lh[kSortBins * kSortKeysHost];
+	for (int t = threadIdx.x; t < kSortBins * kSortKeysHost; t += 256) lh[t] = 0;
 	__syncthreads();
 	const long long chunk = (n + gridDim.x - 1) / gridDim.x, lo = chunk * blockIdx.x, hi = min(lo + chunk, n);
 	const int emax = max(P.e_del, P.e_ins), smax = max(P.bias, P.max_mat);
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void glb_sort_hist_kernel(const bmh_glb_task_t
 		atomicAdd(&lh[bk], 1u);
 	}
 	__syncthreads();
-	for (int t = threadIdx.x; t < kExtBins * kSortKeysHost; t += 256)
+	for (int t = threadIdx.x; t < kSortBins * kSortKeysHost; t += 256)
 		if (lh[t]) atomicAdd(&hist[t], lh[t]);
 }
 
@@ -249,7 +249,7 @@ int launch_global(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_glb_task_t *d_t
 	uint32_t *counts, *lists;
 	if ((rc = sort_tasks_begin(ctx, n, &counts, &lists))) return rc;
 	uint32_t *hist = counts + 16;
-	uint16_t *binkey = (uint16_t *)(hist + (size_t)kExtBins * kSortKeysHost);
+	uint16_t *binkey = (uint16_t *)(hist + (size_t)kSortBins * kSortKeysHost);
 	long long cg = (n + 1023) / 1024;
 	if (cg > 512) cg = 512;
 	hipLaunchKernelGGL(glb_sort_hist_kernel, dim3((unsigned)cg), dim3(256), 0, ctx->stream, d_tasks, d_order, (long long)n, hist,

@@ -24,11 +24,19 @@ __global__ void sw_caps_kernel(const bmh_sw_task_t *__restrict__ tasks, long lon
 //   bin 2: everything else                                           sw_generic_kernel (both passes)
 //   bin 3, 4: like 0, 1 for queries holding an N                     sw_lane_kernel<.., CORR>
 //   bin 5: nothing to do (second pass not wanted)
+//   bin 6: byte mode, cannot overflow, padded query <= 256 columns  sw_lane_kernel<128, CORR>
+//   bin 7: word mode, scores below 512, padded query <= 256 columns sw_lane_kernel<128, CORR, WORD> (250 bp reads)
+__device__ __forceinline__ bool sw_lane_bin(int bin) { return bin < 2 || bin >= 6; }
 __device__ __forceinline__ int sw_bin_of(const DevParams &P, int qlen, uint32_t xtra, int mode)
 {
-	if (mode == 1 || !(xtra & BMH_SW_XBYTE) || qlen < 1 || qlen * P.max_mat + P.sw_shift >= 255) return 2;
+	if (mode == 1 || qlen < 1) return 2;
+	if (!(xtra & BMH_SW_XBYTE)) { // ksw_i16: 8 segments; the two register halves hold roundup8(4*slen) columns each
+		const int half = (((qlen + 7) >> 3) * 4 + 7) & ~7;
+		return half <= 128 && qlen * P.max_mat + P.sw_shift < 512 ? 7 : 2;
+	}
+	if (qlen * P.max_mat + P.sw_shift >= 255) return 2;
 	const int Qp = ((qlen + 15) >> 4) * 16;
-	return Qp <= 80 ? 0 : Qp <= 160 ? 1 : 2;
+	return Qp <= 80 ? 0 : Qp <= 160 ? 1 : Qp <= 256 ? 6 : 2;
 }
 
 constexpr int kSwSortThreads = 256;
@@ -38,8 +46,8 @@ __global__ __launch_bounds__(kSwSortThreads) void sw_hist_kernel(const bmh_sw_ta
                                                                  uint16_t *__restrict__ binkey, int mode, int pass2,
                                                                  const uint8_t *__restrict__ pool, int qfine)
 {
-	__shared__ uint32_t lh[kExtBins * kSortKeysHost];
-	for (int t = threadIdx.x; t < kExtBins * kSortKeysHost; t += kSwSortThreads) lh[t] = 0;
+	__shared__ uint32_t lh[kSortBins * kSortKeysHost];
+	for (int t = threadIdx.x; t < kSortBins * kSortKeysHost; t += kSwSortThreads) lh[t] = 0;
 	__syncthreads();
 	const long long chunk = (n + gridDim.x - 1) / gridDim.x, lo = chunk * blockIdx.x, hi = min(lo + chunk, n);
 	for (long long k = lo + threadIdx.x; k < hi; k += kSwSortThreads) {
@@ -54,7 +62,7 @@ __global__ __launch_bounds__(kSwSortThreads) void sw_hist_kernel(const bmh_sw_ta
 		}
 		if (pass2) { // ksw.c:354: only where start positions are wanted and the first pass reached the threshold
 			const int score = res[k].score;
-			const bool second = bin < 2 && (xtra & BMH_SW_XSTART) && !((xtra & BMH_SW_XSUBO) && score < (int)(xtra & 0xffff)) &&
+			const bool second = sw_lane_bin(bin) && (xtra & BMH_SW_XSTART) && !((xtra & BMH_SW_XSUBO) && score < (int)(xtra & 0xffff)) &&
 			                    res[k].qe >= 0;
 			qlen = res[k].qe + 1;
 			bin = second ? sw_bin_of(P, qlen, xtra, mode) : 5;
@@ -64,14 +72,14 @@ __global__ __launch_bounds__(kSwSortThreads) void sw_hist_kernel(const bmh_sw_ta
 		// lanes of a wave must share ceil(qlen/16) and should share qlen (uniform padding) and the row count
 		// qfine >= 0: all queries of the batch lie in [qfine, qfine+64) (the usual case: one read length) -- six bits tell them
 		// apart and five are left for the row count, so that the lanes of a wave finish within 32 rows of one another
-		const int key = bin >= 2 ? 0 : (!pass2 && qfine >= 0) ? ((qlen - qfine) << 5) | min(rows >> 5, 31) : (min(qlen, 255) << 3) | min(rows >> 7, 7);
+		const int key = !sw_lane_bin(bin) ? 0 : (!pass2 && qfine >= 0) ? ((qlen - qfine) << 5) | min(rows >> 5, 31) : (min(qlen, 255) << 3) | min(rows >> 7, 7);
 		if (bin < 2 && has_n) bin += 3;
 		const int bk = bin * kSortKeysHost + key;
 		binkey[k] = (uint16_t)bk;
 		atomicAdd(&lh[bk], 1u);
 	}
 	__syncthreads();
-	for (int t = threadIdx.x; t < kExtBins * kSortKeysHost; t += kSwSortThreads)
+	for (int t = threadIdx.x; t < kSortBins * kSortKeysHost; t += kSwSortThreads)
 		if (lh[t]) atomicAdd(&hist[t], lh[t]);
 }
 
@@ -116,14 +124,17 @@ int launch_sw(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks,
 	for (int pass2 = 0; pass2 < 2; ++pass2) {
 		if ((rc = sort_tasks_begin(ctx, n, &counts, &lists))) return rc;
 		uint32_t *hist = counts + 16;
-		uint16_t *binkey = (uint16_t *)(hist + (size_t)kExtBins * kSortKeysHost);
+		uint16_t *binkey = (uint16_t *)(hist + (size_t)kSortBins * kSortKeysHost);
 		hipLaunchKernelGGL(sw_hist_kernel, dim3((unsigned)cg), dim3(kSwSortThreads), 0, ctx->stream, d_tasks, (long long)n,
 		                   d_res, ctx->dev, hist, binkey, mode, pass2, d_pool, qfine);
 		if ((rc = sort_tasks_finish(ctx, n, nullptr, (unsigned)cg))) return rc;
-		if ((rc = launch_sw_lane(ctx, 80, false, d_pool, d_tasks, n, d_res, lists + N, counts + 1, d_rm, tcap, grid, pass2, counts + 9))) return rc;
-		if ((rc = launch_sw_lane(ctx, 80, true, d_pool, d_tasks, n, d_res, lists + 4 * N, counts + 4, d_rm, tcap, grid, pass2, counts + 12))) return rc;
-		if ((rc = launch_sw_lane(ctx, 40, false, d_pool, d_tasks, n, d_res, lists, counts, d_rm, tcap, grid, pass2, counts + 8))) return rc;
-		if ((rc = launch_sw_lane(ctx, 40, true, d_pool, d_tasks, n, d_res, lists + 3 * N, counts + 3, d_rm, tcap, grid, pass2, counts + 11))) return rc;
+		// (counts[b] = size of bin b, counts[8 + b] = its chunk cursor; longest columns first)
+		if ((rc = launch_sw_lane(ctx, 128, true, true, d_pool, d_tasks, n, d_res, lists + 7 * N, counts + 7, d_rm, tcap, grid, pass2, counts + 15))) return rc;
+		if (qcap > 160 + 16 && (rc = launch_sw_lane(ctx, 128, true, false, d_pool, d_tasks, n, d_res, lists + 6 * N, counts + 6, d_rm, tcap, grid, pass2, counts + 14))) return rc;
+		if ((rc = launch_sw_lane(ctx, 80, false, false, d_pool, d_tasks, n, d_res, lists + N, counts + 1, d_rm, tcap, grid, pass2, counts + 9))) return rc;
+		if ((rc = launch_sw_lane(ctx, 80, true, false, d_pool, d_tasks, n, d_res, lists + 4 * N, counts + 4, d_rm, tcap, grid, pass2, counts + 12))) return rc;
+		if ((rc = launch_sw_lane(ctx, 40, false, false, d_pool, d_tasks, n, d_res, lists, counts, d_rm, tcap, grid, pass2, counts + 8))) return rc;
+		if ((rc = launch_sw_lane(ctx, 40, true, false, d_pool, d_tasks, n, d_res, lists + 3 * N, counts + 3, d_rm, tcap, grid, pass2, counts + 11))) return rc;
 		if (!pass2 && (rc = launch_sw_generic(ctx, d_pool, d_tasks, n, d_res, lists + 2 * N, counts + 2, qcap, tcap))) return rc;
 	}
 	if (ctx->timing) {

@@ -37,6 +37,7 @@ __device__ __forceinline__ uint32_t pk_subs(uint32_t a, uint32_t b) { return as_
 __device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) { return as_u32(__builtin_elementwise_max(as_us2(a), as_us2(b))); }
 __device__ __forceinline__ uint32_t pk_shr(uint32_t a, int k) { return as_u32(as_us2(a) >> (us2)((unsigned short)k)); }
 __device__ __forceinline__ uint32_t pk_mul(uint32_t a, uint32_t b) { return as_u32(as_us2(a) * as_us2(b)); }
+__device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c) { return as_u32(as_us2(a) * as_us2(b) + as_us2(c)); }
 
 // compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N-1>{})
 template <int N, int I = 0, class F>
@@ -73,8 +74,14 @@ __device__ __forceinline__ int swl_tbase(const SwLaneSeq &s, const DevParams &P,
 // SYM: o_del == o_ins, H-o is shared by the E and F updates.  CORR: queries with N (and waves whose lanes differ in
 // length) -- such columns take a per-lane score correction; the dispatcher keeps those tasks apart, and the plain
 // instantiation groups its lanes by exact query length, so that padding is wave-uniform and needs no correction.
-template <int B, bool SYM, bool CORR>
-__global__ __launch_bounds__(64, B <= 40 ? 3 : 2) void sw_lane_kernel(const uint8_t *__restrict__ pool,
+//
+// WORD: ksw_i16's layout (8 segments instead of 16, no bias in the reference; the kernel keeps the bias, which cancels:
+// max(H+S,0) == sat((H+S+shift)-shift)).  Scores are then kept x128 with a 7-bit column tag, good for scores below 512
+// -- what bwa's callers send in word mode are queries of 250 columns and more (bwamem_pair.c:147), and B = 128 register
+// pairs hold 256 of them.  The substitution byte is fetched into the LOW byte of each half and enters through
+// v_pk_mad_u16 (x128 + H) in place of the add.
+template <int B, bool SYM, bool CORR, bool WORD>
+__global__ __launch_bounds__(64, B <= 40 ? 3 : B <= 80 ? 2 : 1) void sw_lane_kernel(const uint8_t *__restrict__ pool,
                                                                     const bmh_sw_task_t *__restrict__ tasks,
                                                                     const uint32_t *__restrict__ order,
                                                                     const uint32_t *__restrict__ count, long long n,
@@ -84,14 +91,17 @@ __global__ __launch_bounds__(64, B <= 40 ? 3 : 2) void sw_lane_kernel(const uint
                                                                     uint32_t *__restrict__ next_chunk)
 {
 	constexpr int NB = B / 8, NG = (B + 15) / 16;
+	constexpr int SC = WORD ? 7 : 8, SEG = WORD ? 8 : 16; // score scale (bits), segments of the striped layout
+	constexpr uint32_t TAGMAX = (1u << SC) - 1, SBND = WORD ? 512 : 255;
 	__shared__ uint2 srow[8];              // [t] = {biased scores of target base t against A,C,G,T; against N}
 	__shared__ uint32_t wl[(B / 2) * 64]; // v_perm selectors, two column pairs per dword, [word][lane]
 	__shared__ uint32_t ml[CORR ? 2 * ((B + 15) / 16) * 64 : 64]; // N / lane-specific padding bits per 16 columns, [2*g16+kind][lane]
 	const int lane = threadIdx.x;
 	const uint32_t shift = (uint32_t)P.sw_shift;
-	const uint32_t odel = (uint32_t)P.o_del << 8 | (uint32_t)P.o_del << 24, edel = (uint32_t)P.e_del << 8 | (uint32_t)P.e_del << 24;
-	const uint32_t oins = (uint32_t)P.o_ins << 8 | (uint32_t)P.o_ins << 24;
-	const uint32_t shpair = shift << 8 | shift << 24, einspair = (uint32_t)P.e_ins << 8 | (uint32_t)P.e_ins << 24;
+	auto pair = [](uint32_t v) { return v << SC | v << (16 + SC); };
+	const uint32_t odel = pair((uint32_t)P.o_del), edel = pair((uint32_t)P.e_del), oins = pair((uint32_t)P.o_ins);
+	const uint32_t einspair = pair((uint32_t)P.e_ins);
+	const uint32_t shpair = WORD ? shift | shift << 16 : shift << 8 | shift << 24; // as the substitution bytes are placed
 
 	if (lane < 8) {
 		uint32_t lo = 0, nn = 0;
@@ -138,9 +148,10 @@ __global__ __launch_bounds__(64, B <= 40 ? 3 : 2) void sw_lane_kernel(const uint
 		}
 		const bool want_rm = !pass2 && (xtra & BMH_SW_XSUBO);
 		// the dispatcher only sends byte-mode tasks that cannot overflow and fit the register file
-		const bool bad = valid && (qlen < 1 || ((qlen + 15) >> 4) * 16 > 2 * B || !(xtra & BMH_SW_XBYTE) || qlen * P.max_mat + (int)shift >= 255 || tlen > rows_cap);
+		const int slen = (qlen + SEG - 1) / SEG;
+		const bool bad = valid && (qlen < 1 || ((slen * SEG / 2 + 7) & ~7) > B || !(xtra & BMH_SW_XBYTE) != WORD ||
+		                           qlen * P.max_mat + (int)shift >= (int)SBND || tlen > rows_cap);
 		if (bad) atomicExch(err_flag, BMH_E_RANGE);
-		const int slen = (qlen + 15) >> 4;
 		bool pending = valid && !bad;
 		int r_score = 0, r_te = -1, r_qe = 0, r_rows = 0;
 
@@ -149,13 +160,13 @@ __global__ __launch_bounds__(64, B <= 40 ? 3 : 2) void sw_lane_kernel(const uint
 			const int g = __builtin_amdgcn_readlane(slen, first), qlu = __builtin_amdgcn_readlane(qlen, first);
 			const bool act = pending && slen == g && (CORR || qlen == qlu);
 			pending = pending && !act;
-			const int Qp = g * 16;
-			const int Bs = Qp / 2, nb = __builtin_amdgcn_readfirstlane(g); // 8 columns per block: Q = 16*slen splits evenly
+			const int Qp = g * SEG;
+			const int Bs = (Qp / 2 + 7) & ~7, nb = __builtin_amdgcn_readfirstlane(Bs / 8); // 8 columns per block
 			const bool uni_q = __builtin_amdgcn_ballot_w64(act && qlen != qlu) == 0; // padding then is wave-uniform too
 			__syncthreads();
 			for (int jj = lane; jj < B + 8; jj += 64) { // (entries past Bs are never used, only prefetched)
-				auto SH = [&](int c) { return c >= Qp ? 0xffffu : (uni_q && c >= qlu ? 0u : shift << 8); };
-				auto XS = [&](int c) { return (c >= Qp || c % g == 0) ? 0xffffu : (uint32_t)P.e_ins << 8; };
+				auto SH = [&](int c) { return c >= Qp ? 0xffffu : (uni_q && c >= qlu ? 0u : shift << SC); };
+				auto XS = [&](int c) { return (c >= Qp || c % g == 0) ? 0xffffu : (uint32_t)P.e_ins << SC; };
 				xt[jj] = make_uint2(SH(jj) | SH(Bs + jj) << 16, XS(jj + 1) | XS(Bs + jj + 1) << 16);
 			}
 			uint32_t MN[NG], MP[NG]; // per 16 columns: bit k = column is N / lane-specific padding (A low half, B high half)
@@ -199,20 +210,22 @@ __global__ __launch_bounds__(64, B <= 40 ? 3 : 2) void sw_lane_kernel(const uint
 			for (int jj = 0; jj < B; ++jj) H[jj] = E[jj] = 0;
 			bool alive = act && tlen > 0;
 			int gmax = 0, te = -1, qe = 0, nrows = 0;
-			uint32_t hdB = 0, fsB = 0, ffB = 0, prevKA = 0xff;
+			uint32_t hdB = 0, fsB = 0, ffB = 0, prevKA = TAGMAX;
 			uint2 rB = make_uint2(0u, 0u);
 			int tn = alive ? swl_tbase(seq, P, 0) : 4;
 			uint32_t K = 0x0c0c0c0cu;
 			int woff = lane;
 			typedef const uint32_t __attribute__((address_space(4))) *sw_ctab_t;
 			sw_ctab_t xc = (sw_ctab_t)(uintptr_t)xt;
+			uint32_t k128 = 0x00800080u;
+			asm volatile("" : "+s"(k128)); // opaque, or the multiply-add becomes a shift and an add
 
 			for (int s = 0; __builtin_amdgcn_ballot_w64(alive) != 0; ++s) {
 				const uint2 rA = srow[tn];
 				tn = 4;
 				if (alive && s + 1 < tlen) tn = swl_tbase(seq, P, s + 1);
 				const uint32_t plo = rA.x, phi = rB.x;
-				const uint32_t vN = rA.y << 8 | rB.y << 24;
+				const uint32_t vN = WORD ? rA.y | rB.y << 16 : rA.y << 8 | rB.y << 24;
 				asm volatile("" : "+v"(K), "+v"(woff), "+s"(xc)); // keeps the row-invariant selector work inside the row loop
 				uint32_t fs = fsB << 16, ff = ffB << 16, key = 0, hlast = hdB << 16;
 #pragma unroll
@@ -222,7 +235,8 @@ __global__ __launch_bounds__(64, B <= 40 ? 3 : 2) void sw_lane_kernel(const uint
 						const bool flagged = CORR && ((bflag >> b) & 1);
 						// S'(A) << 8 | S'(B) << 24 of column pair c of the block: one v_perm over {row s scores, row s-1 scores}
 						auto subst = [&](int c) {
-							const uint32_t sel = __builtin_amdgcn_perm(wl[(4 * b + c / 2) * 64 + woff], K, (c & 1) ? 0x07000600u : 0x05000400u);
+							const uint32_t sel = __builtin_amdgcn_perm(wl[(4 * b + c / 2) * 64 + woff], K,
+							                                           WORD ? ((c & 1) ? 0x00070006u : 0x00050004u) : ((c & 1) ? 0x07000600u : 0x05000400u));
 							uint32_t sp = __builtin_amdgcn_perm(phi, plo, sel);
 							if (CORR && flagged) { // N columns score mat[t][4]; padding the other lanes do not share scores 0
 								const int jj = 8 * b + c;
@@ -235,7 +249,9 @@ __global__ __launch_bounds__(64, B <= 40 ? 3 : 2) void sw_lane_kernel(const uint
 						// a = H(i-1,j-1) + S' of the column about to be computed; inside a block it is formed while the left
 						// neighbour still holds its previous-row value, so that the new H is written in place; hlast carries
 						// that value across block boundaries and, at the end, over to half B
-						uint32_t a = pk_adds(hlast, subst(0));
+						// (WORD: the byte sits in the low byte of each half and is scaled on the way in; nothing can overflow)
+						auto enter = [&](uint32_t h, uint32_t sp) { return WORD ? pk_mad(sp, k128, h) : pk_adds(h, sp); };
+						uint32_t a = enter(hlast, subst(0));
 #pragma unroll
 						for (int c = 0; c < 8; ++c) {
 							const int jj = 8 * b + c;
@@ -243,9 +259,9 @@ __global__ __launch_bounds__(64, B <= 40 ? 3 : 2) void sw_lane_kernel(const uint
 							const uint32_t m = pk_subs(a, xsh);                  // ksw.c:149-150
 							const uint32_t hp = pk_max(pk_max(m, E[jj]), fs);          // ksw.c:151-153
 							const uint32_t h = pk_max(hp, ff);                          // lazy F, ksw.c:165-176
-							const uint32_t tag = (uint32_t)(255 - jj) * 0x00010001u;
+							const uint32_t tag = (TAGMAX - (uint32_t)jj) * 0x00010001u;
 							key = pk_max(key, h | tag);
-							if (c < 7) a = pk_adds(H[jj], subst(c + 1));
+							if (c < 7) a = enter(H[jj], subst(c + 1));
 							else hlast = H[jj];
 							H[jj] = h;
 							const uint32_t t1 = pk_subs(hp, odel);
@@ -262,8 +278,8 @@ __global__ __launch_bounds__(64, B <= 40 ? 3 : 2) void sw_lane_kernel(const uint
 				prevKA = key & 0xffff;
 				if (s >= 1 && alive) { // row i = s-1 is complete
 					const int i = s - 1;
-					const int ia = (int)(kA >> 8), ib = (int)(kB >> 8), imax = max(ia, ib);
-					const int arg = ia >= ib ? 255 - (int)(kA & 255) : Bs + 255 - (int)(kB & 255);
+					const int ia = (int)(kA >> SC), ib = (int)(kB >> SC), imax = max(ia, ib);
+					const int arg = ia >= ib ? (int)(TAGMAX - (kA & TAGMAX)) : Bs + (int)(TAGMAX - (kB & TAGMAX));
 					if (want_rm) rm[(size_t)i * 64] = (uint16_t)imax;
 					nrows = i + 1;
 					if (imax > gmax) { // ksw.c:190-195
@@ -307,25 +323,27 @@ __global__ __launch_bounds__(64, B <= 40 ? 3 : 2) void sw_lane_kernel(const uint
 	}
 }
 
-int launch_sw_lane(bmh_ctx *ctx, int b, bool corr, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks, int64_t n,
+int launch_sw_lane(bmh_ctx *ctx, int b, bool corr, bool word, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks, int64_t n,
                    bmh_sw_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, uint16_t *d_rm, int rows_cap,
                    int grid, int pass2, uint32_t *d_next)
 {
 	if (n <= 0) return BMH_OK;
 	const long long blocks = std::min<long long>((n + 63) / 64, grid);
 	const bool sym = ctx->dev.o_del == ctx->dev.o_ins;
-#define BMH_LAUNCH_SW(BB, SS, CC)                                                                                        \
-	hipLaunchKernelGGL((sw_lane_kernel<BB, SS, CC>), dim3((unsigned)blocks), dim3(64), 0, ctx->stream, d_pool, d_tasks,  \
-	                   d_order, d_count, (long long)n, d_res, ctx->dev, d_rm, rows_cap, pass2, ctx->d_err, d_next)
-#define BMH_LAUNCH_SW2(BB, CC)                                                                                           \
+#define BMH_LAUNCH_SW(BB, SS, CC, WW)                                                                                    \
+	hipLaunchKernelGGL((sw_lane_kernel<BB, SS, CC, WW>), dim3((unsigned)blocks), dim3(64), 0, ctx->stream, d_pool,       \
+	                   d_tasks, d_order, d_count, (long long)n, d_res, ctx->dev, d_rm, rows_cap, pass2, ctx->d_err, d_next)
+#define BMH_LAUNCH_SW2(BB, CC, WW)                                                                                       \
 	do {                                                                                                                 \
-		if (sym) BMH_LAUNCH_SW(BB, true, CC);                                                                            \
-		else BMH_LAUNCH_SW(BB, false, CC);                                                                               \
+		if (sym) BMH_LAUNCH_SW(BB, true, CC, WW);                                                                        \
+		else BMH_LAUNCH_SW(BB, false, CC, WW);                                                                           \
 	} while (0)
-	if (b == 40 && !corr) BMH_LAUNCH_SW2(40, false);
-	else if (b == 40) BMH_LAUNCH_SW2(40, true);
-	else if (b == 80 && !corr) BMH_LAUNCH_SW2(80, false);
-	else if (b == 80) BMH_LAUNCH_SW2(80, true);
+	if (b == 40 && !corr && !word) BMH_LAUNCH_SW2(40, false, false);
+	else if (b == 40 && !word) BMH_LAUNCH_SW2(40, true, false);
+	else if (b == 80 && !corr && !word) BMH_LAUNCH_SW2(80, false, false);
+	else if (b == 80 && !word) BMH_LAUNCH_SW2(80, true, false);
+	else if (b == 128 && corr && !word) BMH_LAUNCH_SW2(128, true, false); // the 256-column instantiations always correct
+	else if (b == 128 && corr) BMH_LAUNCH_SW2(128, true, true);
 	else return BMH_E_ARG;
 #undef BMH_LAUNCH_SW2
 #undef BMH_LAUNCH_SW

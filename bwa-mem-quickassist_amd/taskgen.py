@@ -20,6 +20,9 @@ WORKLOADS = {
     # C2-C4: 150 bp reads, 2 % subst + 0.25 % ins + 0.25 % del
     "150bp": dict(len_min=150, len_max=150, min_seed_len=19, max_indel=1, p_sub=0.02, p_ins=0.0025, p_del=0.0025,
                   p_n=0.0, p_chimera=0.0),
+    # 2 x 250 bp (MiSeq-like): same error model; ksw_align2 runs in WORD mode from 250 columns on (bwamem_pair.c:147)
+    "250bp": dict(len_min=250, len_max=250, min_seed_len=19, max_indel=1, p_sub=0.02, p_ins=0.0025, p_del=0.0025,
+                  p_n=0.0, p_chimera=0.0),
     # C5: mixed 100-300 bp, indels 1-12, 30 % chimeric tails, 4 % N ("long-band stress")
     "mixed100-300": dict(len_min=100, len_max=300, min_seed_len=19, max_indel=12, p_sub=0.03, p_ins=0.005,
                          p_del=0.005, p_n=0.04, p_chimera=0.3),

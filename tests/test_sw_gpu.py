@@ -51,6 +51,29 @@ def test_sw_matches_oracle_materescue_and_fuzz(mode):
     ctx.close()
 
 
+@pytest.mark.parametrize("mode", ["default", "generic"])
+def test_sw_250bp_class(mode):
+    """Queries of 161-256 columns: byte mode below 250 columns, WORD mode (ksw_i16, 8 segments) from there on -- what
+    mem_matesw sends for 2 x 250 bp reads (reference bwamem_pair.c:147).  Both go to the 256-column register kernels."""
+    ctx = _ctx_with({"BMH_SW_MODE": mode})
+    rng = np.random.default_rng(1250)
+    for p, lens in ((kswlib.make_params(), (161, 256)), (kswlib.make_params(), (250, 250)), (kswlib.make_params(), (249, 251)),
+                    (kswlib.make_params(a=2, b=5), (100, 256)), (kswlib.make_params(o_del=4, e_del=2, o_ins=6, e_ins=1), (200, 256))):
+        ctx.set_params(p)
+        for hard in (False, True):
+            pool, tasks = kswgen.gen_sw_materescue(rng, 700, p, read_len=lens, win=(50, 600), hard=hard)
+            want, _ = kswlib.orc_sw_batch(p, pool, tasks, nthreads=8)
+            _cmp(ctx.sw_batch(pool, tasks), want, tasks, f"{mode} {lens} hard={hard}")
+    # word mode forced on short queries (the function-level contract: any size with or without KSW_XBYTE)
+    p = kswlib.make_params()
+    ctx.set_params(p)
+    pool, tasks = kswgen.gen_sw_materescue(rng, 1500, p, read_len=(3, 256), win=(0, 300), hard=True)
+    tasks["xtra"] &= ~np.uint32(kswlib.KSW_XBYTE)
+    want, _ = kswlib.orc_sw_batch(p, pool, tasks, nthreads=8)
+    _cmp(ctx.sw_batch(pool, tasks), want, tasks, f"{mode} forced word mode")
+    ctx.close()
+
+
 def test_sw_target_from_resident_reference():
     """BMH_F_TPAC: the rescue window is read straight from the 2-bit reference (what mem_matesw gets from
     bns_get_seq, reference bwamem_pair.c:143), the mate reverse-complemented by flags (bwamem_pair.c:130-133)."""
