@@ -162,7 +162,8 @@ __device__ int fm_smem1(const DevBwt &B, int len, const uint8_t *q, int x, int m
 	return ret;
 }
 
-__global__ __launch_bounds__(64) void smem_kernel(DevBwt B, const uint8_t *__restrict__ pool,
+template <int WAVES> // resident waves per SIMD the register allocation aims at
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void smem_kernel(DevBwt B, const uint8_t *__restrict__ pool,
                                                   const uint64_t *__restrict__ read_off, const int *__restrict__ read_len,
                                                   int n_reads, bmh_smem_opt_t O, Intv *scratch, int lcap,
                                                   bmh_smem_call_t *calls, uint32_t *call_read, unsigned long long *cursors,
@@ -365,8 +366,12 @@ int bmh_smem_batch(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const b
 	const int lcap = lmax + 2;
 	int lanes = 64; // reads per wave: fewer when the batch cannot fill the chip anyway (see smem_kernel)
 	if (const char *e = getenv("BMH_SMEM_LANES")) lanes = atoi(e) >= 8 && atoi(e) <= 64 ? atoi(e) : 64; // (A/B knob; fewer measured slower)
-	int grid = (int)std::min<long long>(((long long)n_reads + lanes - 1) / lanes, 4096);
-	while (grid > 1 && (size_t)grid * 3 * (size_t)lcap * 64 * sizeof(Intv) > ((size_t)2 << 30)) grid /= 2; // stacks: at most 2 GB
+	// 105 VGPRs -> 4 waves per SIMD; the 94-register build fits 5: worth it once the batch has more waves than 4 per SIMD
+	// (500 k reads: 20.4 -> 18.9 ms), not below (200 k: 10.0 -> 10.3 ms)
+	int waves = n_reads > 4 * 1024 * 64 ? 5 : 4;
+	if (const char *e = getenv("BMH_SMEM_WAVES")) waves = atoi(e) == 5 ? 5 : 4; // (A/B knob)
+	int grid = (int)std::min<long long>(((long long)n_reads + lanes - 1) / lanes, 1024 * waves);
+	while (grid > 1 && (size_t)grid * 3 * (size_t)lcap * 64 * sizeof(Intv) > ((size_t)6 << 30)) grid /= 2; // stacks: at most 6 GB
 	// device outputs grow until everything fits (the totals are data dependent)
 	// sized from the densest batch this context has seen (calls / intervals per base), so that a steady stream of
 	// batches does not run the kernel twice
@@ -389,10 +394,14 @@ int bmh_smem_batch(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const b
 		BMH_HIP(ctx, hipMemcpyAsync(d + o_off, off.data(), (size_t)n_reads * 8, hipMemcpyHostToDevice, ctx->stream));
 		BMH_HIP(ctx, hipMemcpyAsync(d + o_len, len.data(), (size_t)n_reads * 4, hipMemcpyHostToDevice, ctx->stream));
 		if (ctx->timing) BMH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-		hipLaunchKernelGGL(smem_kernel, dim3((unsigned)grid), dim3(64), 0, ctx->stream, B, (const uint8_t *)(d + o_pool),
-		                   (const uint64_t *)(d + o_off), (const int *)(d + o_len), n_reads, *o, (Intv *)ctx->d_sw.p, lcap,
-		                   (bmh_smem_call_t *)(d + o_calls), (uint32_t *)(d + o_cr), (unsigned long long *)d,
-		                   (unsigned long long)d_calls, (Intv *)(d + o_intv), (unsigned long long)d_intv, (int *)(d + 16), lanes);
+#define BMH_SMEM_LAUNCH(W)                                                                                              \
+	hipLaunchKernelGGL(smem_kernel<W>, dim3((unsigned)grid), dim3(64), 0, ctx->stream, B, (const uint8_t *)(d + o_pool), \
+	                   (const uint64_t *)(d + o_off), (const int *)(d + o_len), n_reads, *o, (Intv *)ctx->d_sw.p, lcap,  \
+	                   (bmh_smem_call_t *)(d + o_calls), (uint32_t *)(d + o_cr), (unsigned long long *)d,               \
+	                   (unsigned long long)d_calls, (Intv *)(d + o_intv), (unsigned long long)d_intv, (int *)(d + 16), lanes)
+		if (waves == 5) BMH_SMEM_LAUNCH(5);
+		else BMH_SMEM_LAUNCH(4);
+#undef BMH_SMEM_LAUNCH
 		BMH_HIP(ctx, hipGetLastError());
 		if (ctx->timing) {
 			BMH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
