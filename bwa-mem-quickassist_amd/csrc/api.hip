@@ -37,6 +37,22 @@ int ensure(bmh_ctx *ctx, DevBuf &b, size_t bytes)
 	return BMH_OK;
 }
 
+int ensure_host(bmh_ctx *ctx, DevBuf &b, size_t bytes)
+{
+	if (bytes <= b.cap) return BMH_OK;
+	size_t cap = std::max(bytes, b.cap * 2);
+	cap = (cap + 4095) & ~(size_t)4095;
+	if (b.p) BMH_HIP(ctx, hipHostFree(b.p));
+	b.p = nullptr, b.cap = 0;
+	hipError_t e = hipHostMalloc(&b.p, cap, hipHostMallocDefault);
+	if (e != hipSuccess) {
+		set_hip_error(ctx, e, "hipHostMalloc(staging)");
+		return BMH_E_NOMEM;
+	}
+	b.cap = cap;
+	return BMH_OK;
+}
+
 static void free_buf(DevBuf &b)
 {
 	if (b.p) (void)hipFree(b.p);
@@ -56,6 +72,56 @@ static int fetch_err(bmh_ctx *ctx)
 	}
 	return e;
 }
+
+// The callers' host buffers are pageable.  Up to kStageMax bytes per direction and call they travel through the
+// context's pinned staging buffers -- one memcpy on the host, then a DMA that does not depend on the runtime's own
+// (slow, process-wide serialised) path for pageable memory; larger transfers go the direct way.
+constexpr size_t kStageMax = (size_t)64 << 20;
+struct Stager {
+	bmh_ctx *ctx;
+	bool up = false, down = false;
+	size_t up_used = 0, down_used = 0;
+	struct Pending {
+		void *dst;
+		size_t off, bytes;
+	} pend[4];
+	int n_pend = 0;
+	int begin(bmh_ctx *c, size_t up_bytes, size_t down_bytes)
+	{
+		ctx = c;
+		int rc;
+		up = up_bytes <= kStageMax, down = down_bytes <= kStageMax;
+		if (up && (rc = ensure_host(c, c->h_up, up_bytes + 256))) return rc;
+		if (down && (rc = ensure_host(c, c->h_down, down_bytes + 256))) return rc;
+		return BMH_OK;
+	}
+	int h2d(void *d_dst, const void *src, size_t bytes)
+	{
+		if (up) {
+			uint8_t *h = (uint8_t *)ctx->h_up.p + up_used;
+			memcpy(h, src, bytes);
+			up_used += (bytes + 63) & ~(size_t)63, src = h;
+		}
+		BMH_HIP(ctx, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+		return BMH_OK;
+	}
+	int d2h(void *dst, const void *d_src, size_t bytes)
+	{
+		void *to = dst;
+		if (down && n_pend < 4) {
+			to = (uint8_t *)ctx->h_down.p + down_used;
+			pend[n_pend++] = Pending{dst, down_used, bytes};
+			down_used += (bytes + 63) & ~(size_t)63;
+		}
+		BMH_HIP(ctx, hipMemcpyAsync(to, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+		return BMH_OK;
+	}
+	void finish() // after the stream has been synchronised
+	{
+		for (int k = 0; k < n_pend; ++k) memcpy(pend[k].dst, (const uint8_t *)ctx->h_down.p + pend[k].off, pend[k].bytes);
+		n_pend = 0;
+	}
+};
 
 } // namespace bmh
 
@@ -143,6 +209,8 @@ int bmh_ctx_destroy(bmh_ctx_t *ctx)
 	if (ctx->bwt_bind) free_bwt_binding(ctx->bwt_bind);
 	if (ctx->d_err) (void)hipFree(ctx->d_err);
 	if (ctx->h_err) (void)hipHostFree(ctx->h_err);
+	if (ctx->h_up.p) (void)hipHostFree(ctx->h_up.p);
+	if (ctx->h_down.p) (void)hipHostFree(ctx->h_down.p);
 	if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
 	if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
 	for (int b = 0; b <= kExtBinsMax; ++b)
@@ -360,14 +428,18 @@ int bmh_extend_batch(bmh_ctx_t *ctx, const uint8_t *pool, size_t pool_bytes, con
 	}
 	if ((rc = ensure(ctx, ctx->d_tasks, (size_t)n * sizeof(bmh_ext_task_t)))) return rc;
 	if ((rc = ensure(ctx, ctx->d_res, (size_t)n * sizeof(bmh_ext_result_t)))) return rc;
-	if (!resident) BMH_HIP(ctx, hipMemcpyAsync(ctx->d_pool.p, pool, pool_bytes, hipMemcpyHostToDevice, ctx->stream));
-	BMH_HIP(ctx, hipMemcpyAsync(ctx->d_tasks.p, tasks, (size_t)n * sizeof(bmh_ext_task_t), hipMemcpyHostToDevice, ctx->stream));
+	Stager st;
+	if ((rc = st.begin(ctx, (resident ? 0 : pool_bytes + 64) + (size_t)n * sizeof(bmh_ext_task_t), (size_t)n * sizeof(bmh_ext_result_t)))) return rc;
+	if (!resident && (rc = st.h2d(ctx->d_pool.p, pool, pool_bytes))) return rc;
+	if ((rc = st.h2d(ctx->d_tasks.p, tasks, (size_t)n * sizeof(bmh_ext_task_t)))) return rc;
 	// launch order: the dispatcher sorts the tasks on the device (bin, length bucket, row estimate)
 	if ((rc = launch_extend(ctx, (const uint8_t *)ctx->d_pool.p, (const bmh_ext_task_t *)ctx->d_tasks.p, n,
 	                        (bmh_ext_result_t *)ctx->d_res.p, nullptr, qmax)))
 		return rc;
-	BMH_HIP(ctx, hipMemcpyAsync(results, ctx->d_res.p, (size_t)n * sizeof(bmh_ext_result_t), hipMemcpyDeviceToHost, ctx->stream));
-	return fetch_err(ctx); // synchronises
+	if ((rc = st.d2h(results, ctx->d_res.p, (size_t)n * sizeof(bmh_ext_result_t)))) return rc;
+	rc = fetch_err(ctx); // synchronises
+	st.finish();
+	return rc;
 }
 
 int bmh_upload_pool(bmh_ctx_t *ctx, const uint8_t *pool, size_t bytes)
@@ -377,7 +449,8 @@ int bmh_upload_pool(bmh_ctx_t *ctx, const uint8_t *pool, size_t bytes)
 	BMH_HIP(ctx, hipSetDevice(ctx->device));
 	ctx->pool_resident = false;
 	if ((rc = ensure(ctx, ctx->d_pool, bytes + 16))) return rc;
-	BMH_HIP(ctx, hipMemcpyAsync(ctx->d_pool.p, pool, bytes, hipMemcpyHostToDevice, ctx->stream));
+	Stager st;
+	if ((rc = st.begin(ctx, bytes, 0)) || (rc = st.h2d(ctx->d_pool.p, pool, bytes))) return rc;
 	BMH_HIP(ctx, hipStreamSynchronize(ctx->stream)); // `pool` may be freed by the caller on return
 	ctx->pool_resident = true, ctx->pool_bytes = bytes;
 	return BMH_OK;
@@ -475,15 +548,20 @@ int bmh_global_batch(bmh_ctx_t *ctx, const uint8_t *pool, size_t pool_bytes, con
 	if ((rc = ensure(ctx, ctx->d_tasks, (size_t)n * sizeof(bmh_glb_task_t)))) return rc;
 	if ((rc = ensure(ctx, ctx->d_res, (size_t)n * sizeof(bmh_glb_result_t)))) return rc;
 	if ((rc = ensure(ctx, ctx->d_cigar, (cigar_words + 4) * 4))) return rc;
-	if (!resident) BMH_HIP(ctx, hipMemcpyAsync(ctx->d_pool.p, pool, pool_bytes, hipMemcpyHostToDevice, ctx->stream));
-	BMH_HIP(ctx, hipMemcpyAsync(ctx->d_tasks.p, tasks, (size_t)n * sizeof(bmh_glb_task_t), hipMemcpyHostToDevice, ctx->stream));
+	Stager st;
+	if ((rc = st.begin(ctx, (resident ? 0 : pool_bytes + 64) + (size_t)n * sizeof(bmh_glb_task_t),
+	                   (size_t)n * sizeof(bmh_glb_result_t) + 64 + cigar_words * 4)))
+		return rc;
+	if (!resident && (rc = st.h2d(ctx->d_pool.p, pool, pool_bytes))) return rc;
+	if ((rc = st.h2d(ctx->d_tasks.p, tasks, (size_t)n * sizeof(bmh_glb_task_t)))) return rc;
 	if ((rc = launch_global(ctx, (const uint8_t *)ctx->d_pool.p, (const bmh_glb_task_t *)ctx->d_tasks.p, n,
 	                        (bmh_glb_result_t *)ctx->d_res.p, (uint32_t *)ctx->d_cigar.p, nullptr, qmax, tmax, wmax)))
 		return rc;
-	BMH_HIP(ctx, hipMemcpyAsync(results, ctx->d_res.p, (size_t)n * sizeof(bmh_glb_result_t), hipMemcpyDeviceToHost, ctx->stream));
-	if (cigar_words)
-		BMH_HIP(ctx, hipMemcpyAsync(cigar_pool, ctx->d_cigar.p, cigar_words * 4, hipMemcpyDeviceToHost, ctx->stream));
-	return fetch_err(ctx);
+	if ((rc = st.d2h(results, ctx->d_res.p, (size_t)n * sizeof(bmh_glb_result_t)))) return rc;
+	if (cigar_words && (rc = st.d2h(cigar_pool, ctx->d_cigar.p, cigar_words * 4))) return rc;
+	rc = fetch_err(ctx);
+	st.finish();
+	return rc;
 }
 
 // ------------------------------------------------------------------ local Smith-Waterman (ksw_align2)
@@ -540,13 +618,26 @@ int bmh_sw_batch(bmh_ctx_t *ctx, const uint8_t *pool, size_t pool_bytes, const b
 	}
 	if ((rc = ensure(ctx, ctx->d_tasks, (size_t)n * sizeof(bmh_sw_task_t)))) return rc;
 	if ((rc = ensure(ctx, ctx->d_res, (size_t)n * sizeof(bmh_sw_result_t)))) return rc;
-	if (!resident) BMH_HIP(ctx, hipMemcpyAsync(ctx->d_pool.p, pool, pool_bytes, hipMemcpyHostToDevice, ctx->stream));
-	BMH_HIP(ctx, hipMemcpyAsync(ctx->d_tasks.p, tasks, (size_t)n * sizeof(bmh_sw_task_t), hipMemcpyHostToDevice, ctx->stream));
+	Stager st;
+	if ((rc = st.begin(ctx, (resident ? 0 : pool_bytes + 64) + (size_t)n * sizeof(bmh_sw_task_t), (size_t)n * sizeof(bmh_sw_result_t)))) return rc;
+	if (!resident && (rc = st.h2d(ctx->d_pool.p, pool, pool_bytes))) return rc;
+	if ((rc = st.h2d(ctx->d_tasks.p, tasks, (size_t)n * sizeof(bmh_sw_task_t)))) return rc;
 	if ((rc = launch_sw(ctx, (const uint8_t *)ctx->d_pool.p, (const bmh_sw_task_t *)ctx->d_tasks.p, n,
 	                    (bmh_sw_result_t *)ctx->d_res.p, qmax, tmax, qmin)))
 		return rc;
-	BMH_HIP(ctx, hipMemcpyAsync(results, ctx->d_res.p, (size_t)n * sizeof(bmh_sw_result_t), hipMemcpyDeviceToHost, ctx->stream));
-	return fetch_err(ctx); // synchronises
+	if ((rc = st.d2h(results, ctx->d_res.p, (size_t)n * sizeof(bmh_sw_result_t)))) return rc;
+	rc = fetch_err(ctx); // synchronises
+	st.finish();
+	return rc;
+}
+
+int bmh_ctx_reserve_staging(bmh_ctx_t *ctx, size_t upload_bytes, size_t download_bytes)
+{
+	if (!ctx) return BMH_E_ARG;
+	int rc;
+	BMH_HIP(ctx, hipSetDevice(ctx->device));
+	if ((rc = ensure_host(ctx, ctx->h_up, upload_bytes)) || (rc = ensure_host(ctx, ctx->h_down, download_bytes))) return rc;
+	return BMH_OK;
 }
 
 int bmh_driver_stats(const bmh_ctx_t *ctx, bmh_driver_stats_t *st)

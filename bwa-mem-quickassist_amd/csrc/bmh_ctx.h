@@ -36,6 +36,9 @@ struct bmh_ctx {
 	int force_kernel = 0; // kernels for qlen<=128: 0 lane-per-task, 1 LDS kernel, 2 one task/wave, 3 four tasks/wave (env BMH_EXT_MODE=lds|reg|grp)
 	bool pool_resident = false; // d_pool holds a pool uploaded by bmh_upload_pool()
 	size_t pool_bytes = 0;
+	// pinned staging of the entry points that move bulk data per call from many host threads at once (the runtime's own
+	// path for pageable memory was the slowest part of a seeding batch: 5-36 ms for 11 MB with eight threads in flight)
+	DevBuf h_up, h_down;
 	int *d_err = nullptr; // device error flag (BMH_E_* or 0)
 	int *h_err = nullptr; // pinned mirror
 	// kernel timing
@@ -55,6 +58,7 @@ namespace bmh {
 
 int set_hip_error(bmh_ctx *ctx, hipError_t e, const char *what);
 int ensure(bmh_ctx *ctx, DevBuf &b, size_t bytes);
+int ensure_host(bmh_ctx *ctx, DevBuf &b, size_t bytes); // same, pinned host memory
 
 #define BMH_HIP(ctx, call)                                                   \
 	do {                                                                     \

@@ -322,7 +322,9 @@ int bmh_sa_batch(bmh_ctx_t *ctx, const uint64_t *k, int64_t n, uint64_t *pos)
 	int rc;
 	BMH_HIP(ctx, hipSetDevice(ctx->device));
 	if ((rc = ensure(ctx, ctx->d_tasks, (size_t)n * 8)) || (rc = ensure(ctx, ctx->d_res, (size_t)n * 8))) return rc;
-	BMH_HIP(ctx, hipMemcpyAsync(ctx->d_tasks.p, k, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+	if ((rc = ensure_host(ctx, ctx->h_up, (size_t)n * 8)) || (rc = ensure_host(ctx, ctx->h_down, (size_t)n * 8))) return rc;
+	memcpy(ctx->h_up.p, k, (size_t)n * 8);
+	BMH_HIP(ctx, hipMemcpyAsync(ctx->d_tasks.p, ctx->h_up.p, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
 	if (ctx->timing) BMH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
 	hipLaunchKernelGGL(sa_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 8192)), dim3(256), 0, ctx->stream, B,
 	                   (const uint64_t *)ctx->d_tasks.p, (long long)n, (uint64_t *)ctx->d_res.p);
@@ -331,8 +333,9 @@ int bmh_sa_batch(bmh_ctx_t *ctx, const uint64_t *k, int64_t n, uint64_t *pos)
 		BMH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
 		ctx->ev_valid = true;
 	}
-	BMH_HIP(ctx, hipMemcpyAsync(pos, ctx->d_res.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+	BMH_HIP(ctx, hipMemcpyAsync(ctx->h_down.p, ctx->d_res.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
 	BMH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	memcpy(pos, ctx->h_down.p, (size_t)n * 8);
 	return BMH_OK;
 }
 
@@ -351,18 +354,24 @@ int bmh_smem_batch(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const b
 	double tt[6] = {now(), 0, 0, 0, 0, 0};
 	int rc, lmax = 1;
 	size_t bytes = 0;
-	std::vector<uint64_t> off((size_t)n_reads);
-	std::vector<int> len((size_t)n_reads);
 	for (int r = 0; r < n_reads; ++r) {
 		if (reads[r].l_seq < 0 || (reads[r].l_seq > 0 && !reads[r].seq)) return BMH_E_ARG;
-		off[(size_t)r] = bytes, len[(size_t)r] = reads[r].l_seq, bytes += (size_t)reads[r].l_seq;
-		lmax = std::max(lmax, reads[r].l_seq);
+		bytes += (size_t)reads[r].l_seq, lmax = std::max(lmax, reads[r].l_seq);
 	}
 	BMH_HIP(ctx, hipSetDevice(ctx->device));
 	ctx->pool_resident = false;
-	std::vector<uint8_t> pool(bytes + 16, 0);
-	for (int r = 0; r < n_reads; ++r)
-		if (reads[r].l_seq) memcpy(pool.data() + off[(size_t)r], reads[r].seq, (size_t)reads[r].l_seq);
+	// host image of the input block [reads | offsets | lengths], built in pinned memory and uploaded with one copy
+	const size_t in_off = (bytes + 16 + 63) & ~(size_t)63, in_len = in_off + (size_t)n_reads * 8, in_bytes = in_len + (size_t)n_reads * 4;
+	if ((rc = ensure_host(ctx, ctx->h_up, in_bytes))) return rc;
+	uint8_t *pool = (uint8_t *)ctx->h_up.p;
+	uint64_t *off = (uint64_t *)(pool + in_off);
+	int *len = (int *)(pool + in_len);
+	memset(pool + bytes, 0, in_off - bytes);
+	for (size_t r = 0, at = 0; r < (size_t)n_reads; ++r) {
+		off[r] = at, len[r] = reads[r].l_seq;
+		if (reads[r].l_seq) memcpy(pool + at, reads[r].seq, (size_t)reads[r].l_seq);
+		at += (size_t)reads[r].l_seq;
+	}
 	const int lcap = lmax + 2;
 	int lanes = 64; // reads per wave: fewer when the batch cannot fill the chip anyway (see smem_kernel)
 	if (const char *e = getenv("BMH_SMEM_LANES")) lanes = atoi(e) >= 8 && atoi(e) <= 64 ? atoi(e) : 64; // (A/B knob; fewer measured slower)
@@ -377,10 +386,12 @@ int bmh_smem_batch(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const b
 	// batches does not run the kernel twice
 	size_t d_calls = std::max<size_t>((size_t)(ctx->smem_calls_per_base * 1.25 * (double)bytes) + 1024, 1024);
 	size_t d_intv = std::max<size_t>((size_t)(ctx->smem_intv_per_base * 1.25 * (double)bytes) + 4096, 4096);
-	std::vector<bmh_smem_call_t> h_calls;
-	std::vector<uint32_t> h_read;
-	std::vector<Intv> h_intv;
+	const bmh_smem_call_t *h_calls = nullptr; // (in the pinned download buffer)
+	const uint32_t *h_read = nullptr;
+	const Intv *h_intv = nullptr;
+	size_t n_calls = 0;
 	unsigned long long totals[2] = {0, 0};
+	if ((rc = ensure_host(ctx, ctx->h_down, 64))) return rc;
 	tt[1] = now();
 	for (int attempt = 0; attempt < 6; ++attempt) {
 		const size_t hdr = 64, o_pool = hdr, o_off = o_pool + ((bytes + 16 + 63) & ~(size_t)63), o_len = o_off + (size_t)n_reads * 8,
@@ -390,9 +401,8 @@ int bmh_smem_batch(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const b
 		if ((rc = ensure(ctx, ctx->d_sw, (size_t)grid * 3 * (size_t)lcap * 64 * sizeof(Intv)))) return rc;
 		uint8_t *d = (uint8_t *)ctx->d_scratch.p;
 		BMH_HIP(ctx, hipMemsetAsync(d, 0, hdr, ctx->stream));
-		BMH_HIP(ctx, hipMemcpyAsync(d + o_pool, pool.data(), bytes + 16, hipMemcpyHostToDevice, ctx->stream));
-		BMH_HIP(ctx, hipMemcpyAsync(d + o_off, off.data(), (size_t)n_reads * 8, hipMemcpyHostToDevice, ctx->stream));
-		BMH_HIP(ctx, hipMemcpyAsync(d + o_len, len.data(), (size_t)n_reads * 4, hipMemcpyHostToDevice, ctx->stream));
+		static_assert(sizeof(uint64_t) == 8 && sizeof(int) == 4, "layout of the input block");
+		BMH_HIP(ctx, hipMemcpyAsync(d + o_pool, pool, in_bytes, hipMemcpyHostToDevice, ctx->stream)); // o_off, o_len follow as in the image
 		if (ctx->timing) BMH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
 #define BMH_SMEM_LAUNCH(W)                                                                                              \
 	hipLaunchKernelGGL(smem_kernel<W>, dim3((unsigned)grid), dim3(64), 0, ctx->stream, B, (const uint8_t *)(d + o_pool), \
@@ -407,18 +417,24 @@ int bmh_smem_batch(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const b
 			BMH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
 			ctx->ev_valid = true;
 		}
-		BMH_HIP(ctx, hipMemcpyAsync(totals, d, 16, hipMemcpyDeviceToHost, ctx->stream));
+		BMH_HIP(ctx, hipMemcpyAsync(ctx->h_down.p, d, 16, hipMemcpyDeviceToHost, ctx->stream));
 		BMH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		memcpy(totals, ctx->h_down.p, 16);
 		ctx->smem_calls_per_base = std::max(ctx->smem_calls_per_base, (double)totals[0] / (double)std::max<size_t>(bytes, 1));
 		ctx->smem_intv_per_base = std::max(ctx->smem_intv_per_base, (double)totals[1] / (double)std::max<size_t>(bytes, 1));
 		tt[2] = now();
 		if (totals[0] <= d_calls && totals[1] <= d_intv) {
-			h_calls.resize((size_t)totals[0]), h_read.resize((size_t)totals[0]), h_intv.resize((size_t)totals[1]);
-			if (totals[0]) {
-				BMH_HIP(ctx, hipMemcpy(h_calls.data(), d + o_calls, (size_t)totals[0] * sizeof(bmh_smem_call_t), hipMemcpyDeviceToHost));
-				BMH_HIP(ctx, hipMemcpy(h_read.data(), d + o_cr, (size_t)totals[0] * 4, hipMemcpyDeviceToHost));
+			n_calls = (size_t)totals[0];
+			const size_t b_calls = n_calls * sizeof(bmh_smem_call_t), b_read = (n_calls * 4 + 63) & ~(size_t)63, b_intv = (size_t)totals[1] * sizeof(Intv);
+			if ((rc = ensure_host(ctx, ctx->h_down, b_calls + b_read + b_intv + 64))) return rc;
+			uint8_t *h = (uint8_t *)ctx->h_down.p;
+			h_calls = (const bmh_smem_call_t *)h, h_read = (const uint32_t *)(h + b_calls), h_intv = (const Intv *)(h + b_calls + b_read);
+			if (n_calls) {
+				BMH_HIP(ctx, hipMemcpyAsync(h, d + o_calls, b_calls, hipMemcpyDeviceToHost, ctx->stream));
+				BMH_HIP(ctx, hipMemcpyAsync(h + b_calls, d + o_cr, n_calls * 4, hipMemcpyDeviceToHost, ctx->stream));
 			}
-			if (totals[1]) BMH_HIP(ctx, hipMemcpy(h_intv.data(), d + o_intv, (size_t)totals[1] * sizeof(Intv), hipMemcpyDeviceToHost));
+			if (totals[1]) BMH_HIP(ctx, hipMemcpyAsync(h + b_calls + b_read, d + o_intv, b_intv, hipMemcpyDeviceToHost, ctx->stream));
+			BMH_HIP(ctx, hipStreamSynchronize(ctx->stream));
 			break;
 		}
 		d_calls = std::max(d_calls, (size_t)totals[0] + 64), d_intv = std::max(d_intv, (size_t)totals[1] + 64);
@@ -432,10 +448,10 @@ int bmh_smem_batch(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const b
 	tt[3] = now();
 	// the device appended in completion order; put every read's calls back in call order and its intervals behind one another
 	std::vector<uint32_t> cnt((size_t)n_reads + 1, 0);
-	for (size_t c = 0; c < h_calls.size(); ++c) ++cnt[(size_t)h_read[c] + 1];
+	for (size_t c = 0; c < n_calls; ++c) ++cnt[(size_t)h_read[c] + 1];
 	for (int r = 0; r < n_reads; ++r) cnt[(size_t)r + 1] += cnt[(size_t)r];
 	for (int r = 0; r <= n_reads; ++r) call_off[r] = cnt[(size_t)r];
-	for (size_t c = 0; c < h_calls.size(); ++c) calls[cnt[h_read[c]] + h_calls[c].rsv] = h_calls[c]; // rsv = sequence number in the read
+	for (size_t c = 0; c < n_calls; ++c) calls[cnt[h_read[c]] + h_calls[c].rsv] = h_calls[c]; // rsv = sequence number in the read
 	uint64_t used = 0;
 	for (int r = 0; r < n_reads; ++r) {
 		intv_off[r] = used;

@@ -69,6 +69,7 @@ void bmh_pool_prewarm(int n)
 		bmh_ctx_t *ctx = 0;
 		slot_t *s = 0;
 		if (bmh_ctx_create(&ctx, dev ? atoi(dev) : 0)) return; /* no GPU: the first real call will say so loudly */
+		(void)bmh_ctx_reserve_staging(ctx, (size_t)8 << 20, (size_t)32 << 20); /* what a phase-1 batch of 8 192 reads moves */
 		pthread_mutex_lock(&g_mu);
 		if (g_n < BMH_POOL_MAX) s = &g_slots[g_n++], s->ctx = ctx, s->have = 0, s->busy = 0;
 		pthread_mutex_unlock(&g_mu);

@@ -252,6 +252,12 @@ typedef struct bmh_driver_stats {
 } bmh_driver_stats_t;
 int bmh_driver_stats(const bmh_ctx_t *ctx, bmh_driver_stats_t *st);
 
+/* The host-buffer entry points stage transfers of up to 64 MB per direction through pinned buffers owned by the context
+ * (they grow on demand).  A caller that creates its contexts ahead of time -- the preload shim does, while the host
+ * program is still loading its index -- can reserve them here, so that the first batch does not pay for the
+ * allocation.  No counterpart in the reference (it has no device). */
+int bmh_ctx_reserve_staging(bmh_ctx_t *ctx, size_t upload_bytes, size_t download_bytes);
+
 /* ------------------------------------------------------------------------------------------------------------
  * Local Smith-Waterman for mate rescue and short chains.
  * Replaces: kswr_t ksw_align2(qlen, query, tlen, target, m, mat, o_del, e_del, o_ins, e_ins, xtra, qry)
