@@ -24,8 +24,10 @@
  * Left extensions read query and window backwards via BMH_F_QREV|BMH_F_TREV
  * instead of materialising reversed copies (bwamem.c:813-817).
  */
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "../../include/bwamem_hip.h"
 
@@ -314,9 +316,18 @@ static int deliver(drv_t *d, int r, rstate_t *rs, const bmh_ext_result_t *x, bmh
 	}
 }
 
+static double now_s(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
 int bmh_chain2aln_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n_reads, const bmh_read_t *reads,
                         const bmh_chain_v *chains, bmh_chain_pre_fn pre, void *pre_ud, bmh_alnreg_v *regs)
 {
+	const int trace = getenv("BMH_DRIVER_TRACE") != 0; /* where a call's time goes, on stderr */
+	double t_trace[4] = {0, 0, 0, 0};
 	drv_t d;
 	rstate_t *rs = 0;
 	chain_win_t *wins = 0;
@@ -333,6 +344,7 @@ int bmh_chain2aln_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n
 	if (!d.p) return BMH_E_ARG;
 	if (n_reads == 0) return BMH_OK;
 	d.reads = reads, d.chains = chains, d.pre = pre, d.pre_ud = pre_ud, d.regs = regs;
+	t_trace[0] = trace ? now_s() : 0;
 
 	/* pass 1: window of every live chain (bwamem.c:740-755) and pool layout */
 	rs = (rstate_t *)calloc((size_t)n_reads, sizeof(rstate_t));
@@ -391,6 +403,7 @@ int bmh_chain2aln_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n
 	if ((rc = bmh_upload_pool(ctx, pool, pool_bytes + 16))) goto done;
 
 	/* rounds */
+	t_trace[1] = trace ? now_s() : 0;
 	n_tasks = 0;
 	for (r = 0; r < n_reads; ++r) {
 		int k = advance(&d, r, &rs[r], &tasks[n_tasks]);
@@ -401,7 +414,9 @@ int bmh_chain2aln_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n
 		int i, m = 0;
 		++d.st.rounds;
 		d.st.ext_tasks += n_tasks;
+		t_trace[3] = trace ? now_s() : 0;
 		if ((rc = bmh_extend_batch(ctx, 0, 0, tasks, n_tasks, res))) goto done;
+		if (trace) t_trace[2] += now_s() - t_trace[3];
 		for (i = 0; i < n_tasks; ++i) { /* compact in place: slot m <= i is free once task i is consumed */
 			bmh_ext_task_t nt;
 			int k;
@@ -413,6 +428,9 @@ int bmh_chain2aln_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n
 		}
 		n_tasks = m;
 	}
+	if (trace)
+		fprintf(stderr, "[bwamem_hip] bmh_chain2aln_batch %d reads: windows+pool+upload %.1f ms, %lld rounds: GPU calls %.1f ms, state machine %.1f ms\n",
+		        n_reads, (t_trace[1] - t_trace[0]) * 1e3, (long long)d.st.rounds, t_trace[2] * 1e3, (now_s() - t_trace[1] - t_trace[2]) * 1e3);
 done:
 	if (rs) for (r = 0; r < n_reads; ++r) free(rs[r].srt);
 	bmh_ctx_set_driver_stats_(ctx, &d.st);

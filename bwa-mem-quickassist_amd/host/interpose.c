@@ -30,11 +30,12 @@
  * synchronise the whole device, collide.  The host work around the calls (chaining, folding) is not limited. */
 static sem_t g_gpu_sem;
 static pthread_once_t g_gpu_once = PTHREAD_ONCE_INIT;
-static void gpu_sem_init(void)
+static int gpu_concurrency(void)
 {
 	const char *e = getenv("BMH_GPU_CONCURRENCY");
-	sem_init(&g_gpu_sem, 0, e && atoi(e) > 0 ? (unsigned)atoi(e) : 8u);
+	return e && atoi(e) > 0 ? atoi(e) : 8;
 }
+static void gpu_sem_init(void) { sem_init(&g_gpu_sem, 0, (unsigned)gpu_concurrency()); }
 static void gpu_enter(void)
 {
 	pthread_once(&g_gpu_once, gpu_sem_init);
@@ -55,6 +56,11 @@ __attribute__((constructor)) static void qa_shim_loaded(void)
 {
 	const char *e = getenv("BMH_PREWARM"), *pl = getenv("LD_PRELOAD");
 	pthread_t t;
+	/* The HIP runtime multiplexes all streams of a process onto 4 hardware queues by default; with 8 host threads inside
+	 * batch calls (16 streams) a thread's small extension kernels then wait behind another thread's 10-20 ms seeding
+	 * kernel that happens to share its queue (measured: phase 1 of a 400 k-read chunk 0.48 s -> 0.21 s with 8 queues).
+	 * Must be in the environment before the runtime initialises; a value the user has set is left alone. */
+	setenv("GPU_MAX_HW_QUEUES", "8", 0);
 	if (e && e[0] == '0') return;
 	if (!pl || !strstr(pl, "libbwamem_hip_dropin")) return; /* only when preloaded into a host program, not when merely dlopen()ed */
 	{ /* ... and only into `<prog> mem ...`: index building, usage errors etc. never touch the GPU */
@@ -542,33 +548,36 @@ static void qa_cigar_slice(void *data, int k, int tid)
 		bmh_pool_put(ctx);
 		gpu_leave();
 	}
+	{ /* into the chunk's table, from this slice's thread (a slot is claimed with a compare-and-swap; nobody reads the table
+	   * before every slice is done) */
+		size_t j;
+		for (j = 0; j < S->n_req; ++j) {
+			const bmh_cigar_req_t *q = &S->reqs[j];
+			cg_entry_t *e;
+			size_t h;
+			if (S->res[j].NM < 0) continue; /* rejected (bwa.c:99): leave it to the reference */
+			for (h = cg_hash(q->qe - q->qb, q->rb, q->re) & (g_cg.cap - 1); !__sync_bool_compare_and_swap(&g_cg.tab[h].used, 0u, 1u);
+			     h = (h + 1) & (g_cg.cap - 1)) {}
+			e = &g_cg.tab[h];
+			e->q = J->reads[q->read].seq + q->qb, e->l = q->qe - q->qb, e->rb = q->rb, e->re = q->re;
+			e->score = S->res[j].score, e->n_cigar = S->res[j].n_cigar, e->NM = S->res[j].NM;
+			e->cigar = S->cig + S->res[j].cigar_off, e->md = S->md + S->res[j].md_off, e->md_len = S->res[j].md_len;
+		}
+	}
 }
 
 static void qa_cigar_cache_build(qa_slice_job_t *J, int n_threads)
 {
-	size_t total = 0, k;
-	int s;
+	size_t total = 0, ub = 0;
+	int s, i;
 	g_cg.n_slices = J->n_slices;
 	g_cg.slices = (cg_slice_t *)calloc((size_t)J->n_slices, sizeof(cg_slice_t));
+	for (i = 0; i < J->n; ++i) ub += J->regs[i].n; /* no slice can ask for more entries than there are regions */
+	for (g_cg.cap = 64; g_cg.cap < 2 * ub; g_cg.cap <<= 1) {}
+	g_cg.tab = (cg_entry_t *)calloc(g_cg.cap, sizeof(cg_entry_t)); /* (untouched pages: the slices' threads fault them in) */
+	if (!g_cg.tab) bmh_tls_die("out of memory for the CIGAR table", BMH_E_NOMEM);
 	kt_for(n_threads, qa_cigar_slice, J, J->n_slices);
 	for (s = 0; s < J->n_slices; ++s) total += g_cg.slices[s].n_req;
-	if (total == 0) return;
-	for (g_cg.cap = 64; g_cg.cap < 2 * total; g_cg.cap <<= 1) {}
-	g_cg.tab = (cg_entry_t *)calloc(g_cg.cap, sizeof(cg_entry_t));
-	for (s = 0; s < J->n_slices; ++s) {
-		const cg_slice_t *S = &g_cg.slices[s];
-		for (k = 0; k < S->n_req; ++k) {
-			const bmh_cigar_req_t *q = &S->reqs[k];
-			cg_entry_t *e;
-			size_t h;
-			if (S->res[k].NM < 0) continue; /* rejected (bwa.c:99): leave it to the reference */
-			for (h = cg_hash(q->qe - q->qb, q->rb, q->re) & (g_cg.cap - 1); g_cg.tab[h].used; h = (h + 1) & (g_cg.cap - 1)) {}
-			e = &g_cg.tab[h];
-			e->q = J->reads[q->read].seq + q->qb, e->l = q->qe - q->qb, e->rb = q->rb, e->re = q->re;
-			e->score = S->res[k].score, e->n_cigar = S->res[k].n_cigar, e->NM = S->res[k].NM;
-			e->cigar = S->cig + S->res[k].cigar_off, e->md = S->md + S->res[k].md_off, e->md_len = S->res[k].md_len, e->used = 1;
-		}
-	}
 	if (getenv("BMH_VERBOSE")) fprintf(stderr, "[bwamem_hip] phase 2: %zu regions through bmh_reg2cigar_batch in %d slices\n", total, J->n_slices);
 }
 
@@ -666,8 +675,13 @@ void mem_process_seqs(const ref_mem_opt_t *opt, const void *bwt, const ref_bntse
 	J.n_slices = opt->n_threads > 0 ? opt->n_threads : 1;
 	opt2 = *opt;
 	if (rescue) { /* the whole chunk's mate rescue, one bmh_matesw_batch per host thread over its share of the pairs */
+		/* a slice holds its place on the GPU for all its rounds, and the rounds of a slice cost latency, not throughput:
+		 * more slices than places would only run one after the other (32 threads: 0.10 s against 0.04 s with 8 slices) */
+		const int all = J.n_slices;
 		g_msw_calls = g_msw_rounds_max = g_msw_bytes = 0;
+		J.n_slices = all < gpu_concurrency() ? all : gpu_concurrency();
 		kt_for(opt->n_threads, qa_matesw_slice, &J, J.n_slices);
+		J.n_slices = all;
 		if (getenv("BMH_VERBOSE"))
 			fprintf(stderr, "[bwamem_hip] mate rescue: %d pairs, %lld ksw_align2 calls in %lld GPU rounds, %lld pool bytes\n", n >> 1,
 			        g_msw_calls, g_msw_rounds_max, g_msw_bytes);

@@ -14,13 +14,22 @@
  * at most three rounds per batch; band choice, the no-gap shortcut (bwa.c:108-114), NM and MD are host
  * work.  Results are bit-identical to the per-region reference calls.
  */
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "../../include/bwamem_hip.h"
 
 const bmh_params_t *bmh_ctx_params_(const bmh_ctx_t *ctx);
 int bmh_upload_pool(bmh_ctx_t *ctx, const uint8_t *pool, size_t bytes);
+
+static double now_s(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 enum { SMALL_CAP = 24 }; /* CIGAR slots reserved per task on the first attempt of a try */
 
@@ -96,6 +105,8 @@ int bmh_reg2cigar_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, const
 	int64_t *owner = 0, k, n_active;
 	size_t pool_bytes = 0, scratch_words = 0, cig_used = 0, md_used = 0;
 	int rc = BMH_OK, round;
+	const int trace = getenv("BMH_DRIVER_TRACE") != 0; /* where a call's time goes, on stderr */
+	double tt[4] = {0, 0, 0, 0}, t0 = 0;
 
 	if (!ctx || n_req < 0 || (n_req > 0 && (!reads || !reqs || !res || !pac))) return BMH_E_ARG;
 	p = bmh_ctx_params_(ctx);
@@ -104,6 +115,7 @@ int bmh_reg2cigar_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, const
 
 	cg = (cg_t *)calloc((size_t)n_req, sizeof(cg_t));
 	if (!cg) return BMH_E_NOMEM;
+	if (trace) tt[0] = now_s();
 	for (k = 0; k < n_req; ++k) { /* layout of the oriented sequence copies */
 		const bmh_cigar_req_t *r = &reqs[k];
 		cg_t *c = &cg[k];
@@ -153,6 +165,7 @@ int bmh_reg2cigar_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, const
 		c->last_sc = -(1 << 30), c->active = 1;
 	}
 	memset(pool + pool_bytes, 0, 16);
+	if (trace) tt[1] = now_s();
 
 	for (round = 0; round < 3; ++round) { /* bwamem.c:1194-1201, all regions in lock step */
 		size_t slot = 0;
@@ -189,8 +202,10 @@ int bmh_reg2cigar_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, const
 		}
 		if (n_active > 0) {
 			int64_t n_big = 0;
+			if (trace) t0 = now_s();
 			if (round == 0) { if ((rc = bmh_upload_pool(ctx, pool, pool_bytes + 16))) goto done; }
 			rc = bmh_global_batch(ctx, 0, 0, tasks, n_active, gres, scratch, slot + 4);
+			if (trace) tt[2] += now_s() - t0;
 			if (rc && rc != BMH_E_CIGAR_CAP) goto done;
 			for (k = 0; k < n_active; ++k) {
 				cg_t *c = &cg[owner[k]];
@@ -228,6 +243,7 @@ int bmh_reg2cigar_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, const
 		if (n_active == 0) break;
 	}
 
+	if (trace) tt[3] = now_s();
 	for (k = 0; k < n_req; ++k) { /* NM / MD and the packed outputs */
 		cg_t *c = &cg[k];
 		size_t md_len = 0;
@@ -242,6 +258,9 @@ int bmh_reg2cigar_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, const
 		res[k].cigar_off = (uint32_t)cig_used, res[k].md_off = (uint32_t)md_used, res[k].md_len = (uint32_t)md_len;
 		cig_used += (size_t)c->n_cigar, md_used += md_len + 1;
 	}
+	if (trace)
+		fprintf(stderr, "[bwamem_hip] bmh_reg2cigar_batch %lld regions: oriented copies %.1f ms, tries %.1f ms (of which upload + GPU calls %.1f ms), NM/MD %.1f ms\n",
+		        (long long)n_req, (tt[1] - tt[0]) * 1e3, (tt[3] - tt[1]) * 1e3, tt[2] * 1e3, (now_s() - tt[3]) * 1e3);
 done:
 	free(cg), free(pool), free(tasks), free(gres), free(owner), free(scratch), free(final_cig);
 	return rc;

@@ -76,6 +76,8 @@ def run(fa, fq, threads, batch, preload, out, ksw_dropin=True):
         env["BMH_KSW_DROPIN"] = "1" if ksw_dropin else "0"
         env["BMH_VERBOSE"] = "1"
         env["BMH_SMEM_TRACE"] = "1"
+        if os.environ.get("BMH_DRIVER_TRACE"):
+            env["BMH_DRIVER_TRACE"] = "1"
     t0 = time.time()
     with open(out, "w") as f:
         p = subprocess.run([reflib.REF_BWA, "mem", "-t", str(threads), "-b", str(batch), fa] + (fq if isinstance(fq, list) else [fq]), stdout=f,
@@ -86,7 +88,10 @@ def run(fa, fq, threads, batch, preload, out, ksw_dropin=True):
         reads += int(m.group(1))
         real += float(m.group(3))
     shim = [l for l in p.stderr.decode().splitlines() if l.startswith("[bwamem_hip]")]
-    return {"reads": reads, "shim": shim[:6] + shim[-8:], "process_seqs_real_s": real, "reads_per_s": reads / real if real else None, "wall_s": wall}
+    drv = [l for l in shim if "bmh_chain2aln_batch" in l]
+    cgr = [l for l in shim if "bmh_reg2cigar_batch" in l and "regions:" in l]
+    shim = [l for l in shim if l not in drv and l not in cgr]
+    return {"reads": reads, "shim": shim[:6] + drv[2:8] + cgr[:4] + shim[-8:], "process_seqs_real_s": real, "reads_per_s": reads / real if real else None, "wall_s": wall}
 
 
 def main():
@@ -121,6 +126,9 @@ def main():
         reads = sim_reads_fast(rng, ref, a.reads, 150)
         reflib.write_fastq(fq, list(reads))
     res = {"genome_bp": a.genome, "repeats": a.repeats, "reads": a.reads, "paired": bool(a.pe), "index_s": t_index, "runs": []}
+    # one untimed DUT run first: on a fresh box the first process to load the HIP runtime and the library's code objects
+    # pays for reading them from disk (seconds), which has nothing to do with the pipeline
+    run(fa, fq, 8, a.batch, True, os.path.join(tmp, "warm.sam"), ksw_dropin=False)
     for t in [int(x) for x in a.threads.split(",")]:
         r = run(fa, fq, t, a.batch, False, os.path.join(tmp, "ref.sam"))
         refsam = [l for l in open(os.path.join(tmp, "ref.sam")) if not l.startswith("@PG")]
