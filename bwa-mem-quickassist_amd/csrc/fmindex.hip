@@ -32,13 +32,6 @@ struct Intv { // == bwtintv_t
 	uint64_t x0, x1, x2, info;
 };
 
-// symbols equal to c among the first n (0..16) symbols of a packed word (symbol 0 in the top two bits)
-__device__ __forceinline__ int fm_count(uint32_t w, uint32_t pat, uint32_t keep)
-{
-	const uint32_t x = w ^ pat; // a symbol equals c <=> both of its bits are now 0
-	return __popc(~(x | x >> 1) & 0x55555555u & keep);
-}
-
 // Four counts / candidates as NAMED members, picked by a select chain: a per-lane index into an array would send the
 // whole array through scratch memory on every extension (it did: 128 bytes written and re-read per bwt_extend).
 struct U4 {
@@ -46,32 +39,47 @@ struct U4 {
 };
 __device__ __forceinline__ uint64_t pick(const U4 &v, int i) { return i == 0 ? v.a : i == 1 ? v.b : i == 2 ? v.c : v.d; }
 
-// bwt_occ4, bwt.c:159-177
-__device__ __forceinline__ U4 fm_occ4(const DevBwt &B, uint64_t k)
+// bwt_occ4, bwt.c:159-177.  The four counts of a word come from three population counts: with x = the symbols' high
+// bits and y = their low bits (both moved to the even bit positions and cut to the prefix that counts),
+// #3 = popc(x & y), #2 = popc(x) - #3, #1 = popc(y) - #3, #0 = symbols counted - the rest; v_bcnt accumulates for free.
+struct Blk { // one 64-byte block: 4 x u64 counts before it, 128 symbols
+	uint4 c0, c1, w0, w1;
+};
+__device__ __forceinline__ Blk fm_load(const DevBwt &B, uint64_t kk) // kk = position with the sentinel taken out
 {
-	U4 r{0, 0, 0, 0};
-	if (k == (uint64_t)-1) return r;
-	k -= (k >= B.primary); // the sentinel is not stored
-	const uint4 *blk = (const uint4 *)(B.bwt + ((k >> 7) << 4));
-	const uint4 c0 = blk[0], c1 = blk[1], w0 = blk[2], w1 = blk[3];
-	const uint32_t w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-	const int full = (int)((k & 127) >> 4), rest = (int)(k & 15) + 1;
-	int n0 = 0, n1 = 0, n2 = 0, n3 = 0;
+	const uint4 *blk = (const uint4 *)(B.bwt + ((kk >> 7) << 4));
+	return Blk{blk[0], blk[1], blk[2], blk[3]};
+}
+__device__ __forceinline__ U4 fm_count4(const Blk &b, uint64_t kk)
+{
+	const uint32_t w[8] = {b.w0.x, b.w0.y, b.w0.z, b.w0.w, b.w1.x, b.w1.y, b.w1.z, b.w1.w};
+	const int full = (int)((kk & 127) >> 4), rest = (int)(kk & 15) + 1; // whole words, symbols of the next one (symbol 0 = top bits)
+	uint32_t px = 0, py = 0, pxy = 0;
 #pragma unroll
 	for (int j = 0; j < 8; ++j) {
-		const uint32_t keep = j < full ? 0xffffffffu : j == full ? 0xffffffffu << (32 - 2 * rest) : 0u;
-		n0 += fm_count(w[j], 0x00000000u, keep), n1 += fm_count(w[j], 0x55555555u, keep);
-		n2 += fm_count(w[j], 0xaaaaaaaau, keep), n3 += fm_count(w[j], 0xffffffffu, keep);
+		const uint32_t keep = (j < full ? 0xffffffffu : j == full ? 0xffffffffu << (32 - 2 * rest) : 0u) & 0x55555555u;
+		const uint32_t x = (w[j] >> 1) & keep, y = w[j] & keep;
+		px += (uint32_t)__popc(x), py += (uint32_t)__popc(y), pxy += (uint32_t)__popc(x & y);
 	}
-	r.a = ((uint64_t)c0.y << 32 | c0.x) + (uint64_t)n0, r.b = ((uint64_t)c0.w << 32 | c0.z) + (uint64_t)n1;
-	r.c = ((uint64_t)c1.y << 32 | c1.x) + (uint64_t)n2, r.d = ((uint64_t)c1.w << 32 | c1.z) + (uint64_t)n3;
+	const uint32_t n3 = pxy, n2 = px - pxy, n1 = py - pxy, n0 = (uint32_t)(kk & 127) + 1 - n1 - n2 - n3;
+	U4 r;
+	r.a = ((uint64_t)b.c0.y << 32 | b.c0.x) + (uint64_t)n0, r.b = ((uint64_t)b.c0.w << 32 | b.c0.z) + (uint64_t)n1;
+	r.c = ((uint64_t)b.c1.y << 32 | b.c1.x) + (uint64_t)n2, r.d = ((uint64_t)b.c1.w << 32 | b.c1.z) + (uint64_t)n3;
 	return r;
+}
+__device__ __forceinline__ U4 fm_occ4(const DevBwt &B, uint64_t k)
+{
+	if (k == (uint64_t)-1) return U4{0, 0, 0, 0};
+	k -= (k >= B.primary); // the sentinel is not stored
+	return fm_count4(fm_load(B, k), k);
 }
 
 // bwt_extend, bwt.c:261-274, for ONE base c (the only one of the four the caller goes on with)
 __device__ __forceinline__ Intv fm_extend(const DevBwt &B, const Intv &ik, int c, bool is_back)
 {
 	const uint64_t a = is_back ? ik.x0 : ik.x1, b = is_back ? ik.x1 : ik.x0; // a = x[!is_back], b = x[is_back]
+	// (reading the block once when both ends of a small interval share it -- bwt_2occ4, bwt.c:188-219 -- was measured and
+	// is slower here: the second read hits the first one's cache line anyway and the branch costs more than it saves)
 	const U4 tk = fm_occ4(B, a - 1), tl = fm_occ4(B, a - 1 + ik.x2);
 	const U4 sz{tl.a - tk.a, tl.b - tk.b, tl.c - tk.c, tl.d - tk.d}; // ok[i].x[2]
 	const U4 l2{B.L2[0], B.L2[1], B.L2[2], B.L2[3]};
