@@ -97,6 +97,7 @@ __global__ __launch_bounds__(64, B <= 40 ? 3 : B <= 80 ? 2 : 1) void sw_lane_ker
 	__shared__ uint32_t wl[(B / 2) * 64]; // v_perm selectors, two column pairs per dword, [word][lane]
 	__shared__ uint32_t ml[CORR ? 2 * ((B + 15) / 16) * 64 : 64]; // N / lane-specific padding bits per 16 columns, [2*g16+kind][lane]
 	const int lane = threadIdx.x;
+	if (count && *count == 0) return; // an empty bin (most launches of a small batch are): nothing to set up
 	const uint32_t shift = (uint32_t)P.sw_shift;
 	auto pair = [](uint32_t v) { return v << SC | v << (16 + SC); };
 	const uint32_t odel = pair((uint32_t)P.o_del), edel = pair((uint32_t)P.e_del), oins = pair((uint32_t)P.o_ins);
