@@ -233,6 +233,175 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
 	}
 }
 
+// ---- the same work with ONE bwt_extend site that all lanes reach together ---------------------------------------------------------
+// In smem_kernel above the 64 reads of a wave sit in different loops of bwt_smem1 most of the time, and the wave issues every
+// path for the few lanes on it: measured 25 % of the VALU lanes active (SQ_THREAD_CYCLES_VALU / 64 SQ_ACTIVE_INST_VALU), at
+// about 200 instructions per extension.  Here a lane is a small machine {next read, next call, forward at i, backward at (i,j)}:
+// per trip it first runs the transitions that need no extension (setting up a call, closing the forward pass, emitting a
+// finished call, drawing the next read from a shared counter), then every lane that has an extension to do does it in the
+// same instruction stream, then consumes the result.  Same calls, same intervals, same order within a read as above.
+// Emitting a finished call is a chain of dependent memory operations (two returning atomics, the intervals read back from the
+// lane's stack and written out, the next call's first bases): done the moment a lane gets there it would stall the other 63
+// on almost every trip.  A lane that has finished a call therefore WAITS (PH_EMIT) until `emit_min` lanes of the wave do, or
+// nobody has an extension left; then they emit, and set up their next calls, together.
+enum { PH_READ = 0, PH_CALL = 1, PH_FWD = 2, PH_BWD = 3, PH_EMIT = 4, PH_DONE = 5 };
+
+template <int WAVES>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) void smem_conv_kernel(
+    DevBwt B, const uint8_t *__restrict__ pool, const uint64_t *__restrict__ read_off, const int *__restrict__ read_len, int n_reads,
+    bmh_smem_opt_t O, Intv *scratch, int lcap, bmh_smem_call_t *calls, uint32_t *call_read, unsigned long long *cursors,
+    unsigned long long call_cap, Intv *intv, unsigned long long intv_cap, int *overflow, int emit_min)
+{
+	const int lane = threadIdx.x;
+	Intv *slab = scratch + (size_t)blockIdx.x * 3 * (size_t)lcap * 64 + lane;
+	Stack prev{slab}, curr{slab + (size_t)lcap * 64};
+	int emit_n = 0, emit_ret = 0;
+	const Stack mem{slab + 2 * (size_t)lcap * 64};
+	const U4 l2{B.L2[0], B.L2[1], B.L2[2], B.L2[3]}, l2n{B.L2[1], B.L2[2], B.L2[3], B.L2[4]};
+
+	int phase = PH_READ;
+	// read
+	long long r = 0;
+	const uint8_t *q = pool;
+	int len = 0, split_len = 0, start = 0, seq = 0;
+	bool pend_split = false, is_split = false;
+	int x2 = 0, mi2 = 0;
+	// call
+	int x = 0, min_intv = 1, ret = 0, i = 0, j = 0, np = 0, nc = 0, nm = 0, cb = -1;
+	bool rev = false; // the first backward row walks the forward pass's stack from its top (bwt.c:316 reverses it instead)
+	uint64_t mem_start = 0, last_x2 = 0;
+	Intv ik{}, p{};
+
+	// the call is over: emit it (smem_next2's bookkeeping, bwamem.c:118-162) and decide what comes next
+	auto finish_call = [&](int n, int ret_) {
+		int mx = 0, mxk = 0;
+		if (!is_split)
+			for (int k = 0; k < n; ++k) { // the longest match, first of equals (mem holds them back to front)
+				const Intv v = mem[n - 1 - k];
+				const int l = (int)((uint32_t)v.info - (uint32_t)(v.info >> 32));
+				if (mx < l) mx = l, mxk = n - 1 - k;
+			}
+		const unsigned long long ci = atomicAdd(&cursors[0], 1ull), base = atomicAdd(&cursors[1], (unsigned long long)n);
+		if (ci < call_cap && base + n <= intv_cap) {
+			bmh_smem_call_t c;
+			c.x = x, c.min_intv = is_split ? mi2 : O.start_width, c.ret = ret_, c.n = n, c.first = (uint32_t)base, c.rsv = (uint32_t)seq;
+			calls[ci] = c, call_read[ci] = (uint32_t)r;
+			for (int k = 0; k < n; ++k) intv[base + k] = mem[n - 1 - k];
+		} else atomicExch(overflow, 1);
+		++seq;
+		if (!is_split) {
+			start = ret_;
+			if (n > 0 && split_len > 0 && mx >= split_len) {
+				const Intv v = mem[mxk];
+				if (v.x2 <= (uint64_t)O.split_width)
+					pend_split = true, x2 = (int)(((uint32_t)v.info + (uint32_t)(v.info >> 32)) >> 1), mi2 = (int)v.x2 + 1;
+			}
+		}
+		phase = PH_CALL;
+	};
+	// the forward pass is over (bwt.c:312-318): its stack becomes the first backward row, longest match first
+	auto end_forward = [&]() {
+		ret = (int)curr[nc - 1].info;
+		np = nc, rev = true;
+		{ const Stack t = curr; curr = prev, prev = t; }
+		i = x - 1, cb = i < 0 ? -1 : q[i] < 4 ? q[i] : -1;
+		j = 0, nc = 0, nm = 0, last_x2 = 0, mem_start = 0;
+		phase = PH_BWD;
+	};
+
+	auto call_over = [&](int n, int ret_) { emit_n = n, emit_ret = ret_, phase = PH_EMIT; };
+
+	for (;;) {
+		// ---- finished calls, in batches
+		{
+			const unsigned long long waiting = __builtin_amdgcn_ballot_w64(phase == PH_EMIT);
+			const unsigned long long busy = __builtin_amdgcn_ballot_w64(phase == PH_FWD || phase == PH_BWD);
+			if (waiting != 0 && (__popcll(waiting) >= emit_min || busy == 0) && phase == PH_EMIT) finish_call(emit_n, emit_ret);
+		}
+		// ---- transitions that need no extension
+		while (phase <= PH_BWD) {
+			if (phase == PH_READ) {
+				r = (long long)atomicAdd(&cursors[3], 1ull);
+				if (r >= n_reads) { phase = PH_DONE; break; }
+				q = pool + read_off[r], len = read_len[r];
+				split_len = min(O.split_len, len); // bwamem.c:213
+				start = 0, seq = 0, pend_split = false;
+				phase = PH_CALL;
+			}
+			if (phase == PH_CALL) {
+				if (pend_split) x = x2, min_intv = mi2, pend_split = false, is_split = true; // re-seeding from the middle of the longest match
+				else {
+					while (start < len && q[start] > 3) ++start;
+					if (start >= len) { phase = PH_READ; continue; }
+					x = start, min_intv = O.start_width, is_split = false;
+				}
+				if (min_intv < 1) min_intv = 1;
+				if (q[x] > 3) { call_over(0, x + 1); break; } // bwt.c:295
+				const int c = q[x];
+				ik.x0 = pick(l2, c) + 1, ik.x2 = pick(l2n, c) - pick(l2, c), ik.x1 = pick(l2, 3 - c) + 1, ik.info = (uint64_t)x + 1; // bwt_set_intv
+				i = x + 1, nc = 0;
+				phase = PH_FWD;
+			}
+			if (phase == PH_FWD) {
+				if (i < len && q[i] < 4) break; // an extension to do
+				curr[nc++] = ik;                // an ambiguous base or the end of the read (bwt.c:308-312)
+				end_forward();
+			}
+			if (phase == PH_BWD) {
+				if (cb >= 0) { // an extension to do, of prev[j]
+					p = prev[rev ? np - 1 - j : j];
+					break;
+				}
+				// the start of the read or an ambiguous base ends every interval; only the first can still be new (bwt.c:327-333)
+				if (nm == 0 || (uint64_t)(i + 1) < mem_start) {
+					Intv m = prev[rev ? np - 1 : 0];
+					m.info |= (uint64_t)(i + 1) << 32;
+					mem[nm++] = m;
+				}
+				call_over(nm, ret);
+			}
+		}
+		if (__builtin_amdgcn_ballot_w64(phase != PH_DONE) == 0) break;
+		// ---- the extension, for every lane that has one
+		Intv o{};
+		if (phase == PH_FWD || phase == PH_BWD) { // ONE site, so the lanes go through it together
+			const bool back = phase == PH_BWD;
+			const Intv in = back ? p : ik;
+			o = fm_extend(B, in, back ? cb : 3 - q[i], back);
+		}
+		// ---- what it means
+		if (phase == PH_FWD) { // bwt.c:300-307
+			bool over = false;
+			if (o.x2 != ik.x2) {
+				curr[nc++] = ik;
+				over = o.x2 < (uint64_t)min_intv;
+			}
+			if (over) end_forward();
+			else ik = o, ik.info = (uint64_t)i + 1, ++i;
+		} else if (phase == PH_BWD) { // bwt.c:324-340
+			if (o.x2 < (uint64_t)min_intv) {
+				if (nc == 0 && (nm == 0 || (uint64_t)(i + 1) < mem_start)) {
+					Intv m = p;
+					m.info |= (uint64_t)(i + 1) << 32;
+					mem[nm++] = m, mem_start = (uint64_t)(i + 1);
+				}
+			} else if (nc == 0 || o.x2 != last_x2) {
+				Intv m = o;
+				m.info = p.info;
+				curr[nc++] = m, last_x2 = o.x2;
+			}
+			if (++j == np) { // the row is done
+				if (nc == 0) call_over(nm, ret);
+				else {
+					{ const Stack t = curr; curr = prev, prev = t; }
+					np = nc, rev = false, --i, cb = i < 0 ? -1 : q[i] < 4 ? q[i] : -1;
+					j = 0, nc = 0, last_x2 = 0;
+				}
+			}
+		}
+	}
+}
+
 // bwt_sa, bwt.c:85-95
 __global__ void sa_kernel(DevBwt B, const uint64_t *__restrict__ ks, long long n, uint64_t *__restrict__ pos)
 {
@@ -385,6 +554,14 @@ int bmh_smem_batch(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const b
 	if (const char *e = getenv("BMH_SMEM_LANES")) lanes = atoi(e) >= 8 && atoi(e) <= 64 ? atoi(e) : 64; // (A/B knob; fewer measured slower)
 	// 105 VGPRs -> 4 waves per SIMD; the 94-register build fits 5: worth it once the batch has more waves than 4 per SIMD
 	// (500 k reads: 20.4 -> 18.9 ms), not below (200 k: 10.0 -> 10.3 ms)
+	int emit_min = 16;
+	if (const char *e = getenv("BMH_SMEM_EMIT")) emit_min = atoi(e) >= 1 && atoi(e) <= 64 ? atoi(e) : 16; // (tuning knob)
+	// Two kernels, same results.  smem_conv_kernel (one extension site, 46 % of the VALU lanes active against 25 %, but about
+	// twice the instructions around each extension) has the shorter critical path: 8 192 reads 3.86 against 4.29 ms, 65 536
+	// reads 4.80 against 5.36 ms -- the batch sizes of the pipeline.  Once the batch fills the chip several times over the
+	// loop-per-lane kernel's lower instruction count wins: 1 M reads 32.1 against 38.1 ms.  BMH_SMEM_KERNEL=conv|loops forces one.
+	bool conv = n_reads <= 128 * 1024;
+	if (const char *e = getenv("BMH_SMEM_KERNEL")) conv = strcmp(e, "loops") != 0;
 	int waves = n_reads > 4 * 1024 * 64 ? 5 : 4;
 	if (const char *e = getenv("BMH_SMEM_WAVES")) waves = atoi(e) == 5 ? 5 : 4; // (A/B knob)
 	int grid = (int)std::min<long long>(((long long)n_reads + lanes - 1) / lanes, 1024 * waves);
@@ -417,8 +594,16 @@ int bmh_smem_batch(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const b
 	                   (const uint64_t *)(d + o_off), (const int *)(d + o_len), n_reads, *o, (Intv *)ctx->d_sw.p, lcap,  \
 	                   (bmh_smem_call_t *)(d + o_calls), (uint32_t *)(d + o_cr), (unsigned long long *)d,               \
 	                   (unsigned long long)d_calls, (Intv *)(d + o_intv), (unsigned long long)d_intv, (int *)(d + 16), lanes)
-		if (waves == 5) BMH_SMEM_LAUNCH(5);
+#define BMH_SMEM_LAUNCH_CONV(W)                                                                                         \
+	hipLaunchKernelGGL(smem_conv_kernel<W>, dim3((unsigned)grid), dim3(64), 0, ctx->stream, B, (const uint8_t *)(d + o_pool), \
+	                   (const uint64_t *)(d + o_off), (const int *)(d + o_len), n_reads, *o, (Intv *)ctx->d_sw.p, lcap,  \
+	                   (bmh_smem_call_t *)(d + o_calls), (uint32_t *)(d + o_cr), (unsigned long long *)d,               \
+	                   (unsigned long long)d_calls, (Intv *)(d + o_intv), (unsigned long long)d_intv, (int *)(d + 16), emit_min)
+		if (conv && waves == 5) BMH_SMEM_LAUNCH_CONV(5);
+		else if (conv) BMH_SMEM_LAUNCH_CONV(4);
+		else if (waves == 5) BMH_SMEM_LAUNCH(5);
 		else BMH_SMEM_LAUNCH(4);
+#undef BMH_SMEM_LAUNCH_CONV
 #undef BMH_SMEM_LAUNCH
 		BMH_HIP(ctx, hipGetLastError());
 		if (ctx->timing) {

@@ -10,7 +10,13 @@ from test_kernel_families_gpu import _ctx_with
 pytestmark = pytest.mark.gpu
 
 
-def test_smem_and_sa_match_reference_fixture():
+# both kernels behind bmh_smem_batch (the library picks by batch size): one extension site for all lanes / a loop nest per lane
+KERNELS = ["conv", "loops"]
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_smem_and_sa_match_reference_fixture(kernel, monkeypatch):
+    monkeypatch.setenv("BMH_SMEM_KERNEL", kernel)
     cb, keep, raw, opt, reads, per, sa_k, sa_pos = kswlib.golden_fmindex()
     ctx = _ctx_with({})
     with pytest.raises(Exception):  # no index on the device yet
@@ -23,8 +29,10 @@ def test_smem_and_sa_match_reference_fixture():
     ctx.close()
 
 
-def test_smem_matches_oracle_on_many_reads():
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_smem_matches_oracle_on_many_reads(kernel, monkeypatch):
     """More and longer reads than the fixture holds (ragged lengths, N runs, empty reads), against the oracle."""
+    monkeypatch.setenv("BMH_SMEM_KERNEL", kernel)
     cb, keep, raw, opt, reads, per, sa_k, sa_pos = kswlib.golden_fmindex()
     rng = np.random.default_rng(191)
     # reads cut from the fixture's own reads (they come from the indexed genome), re-mutated and recombined
