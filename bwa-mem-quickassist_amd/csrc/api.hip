@@ -176,7 +176,9 @@ int bmh_ctx_create(bmh_ctx_t **out, int device)
 	    (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess ||
 	    (e = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking)) != hipSuccess ||
 	    (e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)) != hipSuccess ||
-	    (e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming)) != hipSuccess) {
+	    (e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming)) != hipSuccess ||
+	    (e = hipStreamCreateWithFlags(&ctx->aux2_stream, hipStreamNonBlocking)) != hipSuccess ||
+	    (e = hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming)) != hipSuccess) {
 		fprintf(stderr, "[bwamem_hip] context creation failed: %s\n", hipGetErrorString(e));
 		bmh_ctx_destroy(ctx);
 		return BMH_E_NODEVICE;
@@ -191,6 +193,7 @@ int bmh_ctx_create(bmh_ctx_t **out, int device)
 	if (const char *m = getenv("BMH_GLB_MODE")) ctx->glb_mode = !strcmp(m, "wave") ? 1 : 0;
 	if (const char *m = getenv("BMH_SW_MODE")) ctx->sw_mode = !strcmp(m, "generic") ? 1 : 0;
 	if (const char *m = getenv("BMH_GRID_MULT")) ctx->grid_mult = atoi(m) > 0 ? atoi(m) : 1;
+	if (const char *m = getenv("BMH_EXT_SCHED")) ctx->ext_sched = atoi(m) >= 0 && atoi(m) <= 3 ? atoi(m) : -1;
 	*out = ctx;
 	return BMH_OK;
 }
@@ -221,6 +224,8 @@ int bmh_ctx_destroy(bmh_ctx_t *ctx)
 	if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
 	if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
 	if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+	if (ctx->ev_join2) (void)hipEventDestroy(ctx->ev_join2);
+	if (ctx->aux2_stream) (void)hipStreamDestroy(ctx->aux2_stream);
 	if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
 	delete ctx;
 	return BMH_OK;

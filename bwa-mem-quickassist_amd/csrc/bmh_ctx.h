@@ -33,6 +33,7 @@ struct bmh_ctx {
 	int sw_mode = 0;  // 0 register kernels where they fit, 1 slab kernel only (env BMH_SW_MODE=generic)
 	DevBuf d_bins; // per-launch bin lists of the extension dispatcher: 4 counters + 4 x n task indices
 	int grid_mult = 1;    // env BMH_GRID_MULT: persistent grid = resident waves x this (tuning knob)
+	int ext_sched = -1;   // env BMH_EXT_SCHED: launch order / streams of the extension bins, -1 = by query length (see launch_extend)
 	int force_kernel = 0; // kernels for qlen<=128: 0 lane-per-task, 1 LDS kernel, 2 one task/wave, 3 four tasks/wave (env BMH_EXT_MODE=lds|reg|grp)
 	bool pool_resident = false; // d_pool holds a pool uploaded by bmh_upload_pool()
 	size_t pool_bytes = 0;
@@ -49,6 +50,8 @@ struct bmh_ctx {
 	hipEvent_t ev_bin_end[kExtBinsMax + 1] = {}; // ... and their end (bins run on two streams, see launch_extend)
 	hipStream_t aux_stream = nullptr;            // the few long flanks (bins 3-5) run beside the lane kernels
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+	hipStream_t aux2_stream = nullptr; // ... and the two short-query bins beside the 128-column one
+	hipEvent_t ev_join2 = nullptr;
 	bool ev_bin_valid = false;
 	std::string last_error;
 	bmh_driver_stats_t dstats{};

@@ -166,10 +166,19 @@ int launch_extend(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_t
 	hipStream_t main_s = ctx->stream;
 	BMH_HIP(ctx, hipEventRecord(ctx->ev_fork, main_s));
 	BMH_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
-	static const int order[kExtBins] = {3, 4, 5, 0, 1, 2};
+	static const int orders[4][kExtBins] = {{3, 4, 5, 0, 1, 2}, {3, 4, 5, 2, 1, 0}, {3, 4, 5, 2, 1, 0}, {3, 4, 5, 2, 1, 0}};
+	// 0: short bins first; 1: long bins first; 2: bins 0-1 behind the long flanks on the second stream, beside bin 2;
+	// 3: bins 0-1 on a third stream of their own (A/B knob BMH_EXT_SCHED)
+	// Default: long bins first.  When no query is longer than 160 (150 bp reads: bins 3-5 hold a handful of tasks) the two
+	// short-query bins go behind them on the second stream and run beside the 128-column bin, whose two waves per SIMD leave
+	// issue slots free: 4.61 -> 4.41 ms per 1 M reads.  With many long flanks (100-300 bp reads) that delays bins 3-4, which
+	// are the critical path there (17.8 against 16.8 ms), so they keep the second stream to themselves.
+	const int sched = ctx->ext_sched >= 0 ? ctx->ext_sched : qmax <= 160 ? 2 : 1;
+	const int *order = orders[sched];
+	if (sched == 3) BMH_HIP(ctx, hipStreamWaitEvent(ctx->aux2_stream, ctx->ev_fork, 0));
 	for (int k = 0; k < kExtBins; ++k) {
 		const int b = order[k];
-		ctx->stream = b >= 3 ? ctx->aux_stream : main_s; // the launchers enqueue on ctx->stream
+		ctx->stream = b >= 3 ? ctx->aux_stream : b < 2 && sched == 2 ? ctx->aux_stream : b < 2 && sched == 3 ? ctx->aux2_stream : main_s; // the launchers enqueue on ctx->stream
 		if (tm) {
 			rc = (int)hipEventRecord(ctx->ev_bin[b], ctx->stream);
 			if (rc) { ctx->stream = main_s; return set_hip_error(ctx, (hipError_t)rc, "hipEventRecord"); }
@@ -196,6 +205,10 @@ int launch_extend(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_t
 	ctx->stream = main_s;
 	BMH_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->aux_stream));
 	BMH_HIP(ctx, hipStreamWaitEvent(main_s, ctx->ev_join, 0));
+	if (sched == 3) {
+		BMH_HIP(ctx, hipEventRecord(ctx->ev_join2, ctx->aux2_stream));
+		BMH_HIP(ctx, hipStreamWaitEvent(main_s, ctx->ev_join2, 0));
+	}
 	if (tm) {
 		BMH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
 		ctx->ev_valid = ctx->ev_bin_valid = true;
