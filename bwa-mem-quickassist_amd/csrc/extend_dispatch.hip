@@ -166,7 +166,7 @@ int launch_extend(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_t
 	hipStream_t main_s = ctx->stream;
 	BMH_HIP(ctx, hipEventRecord(ctx->ev_fork, main_s));
 	BMH_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
-	static const int orders[4][kExtBins] = {{3, 4, 5, 0, 1, 2}, {3, 4, 5, 2, 1, 0}, {3, 4, 5, 2, 1, 0}, {3, 4, 5, 2, 1, 0}};
+	static const int orders[5][kExtBins] = {{3, 4, 5, 0, 1, 2}, {3, 4, 5, 2, 1, 0}, {3, 4, 5, 2, 1, 0}, {3, 4, 5, 2, 1, 0}, {2, 1, 0, 3, 4, 5}};
 	// 0: short bins first; 1: long bins first; 2: bins 0-1 behind the long flanks on the second stream, beside bin 2;
 	// 3: bins 0-1 on a third stream of their own (A/B knob BMH_EXT_SCHED)
 	// Default: long bins first.  When no query is longer than 160 (150 bp reads: bins 3-5 hold a handful of tasks) the two
@@ -178,7 +178,7 @@ int launch_extend(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_t
 	if (sched == 3) BMH_HIP(ctx, hipStreamWaitEvent(ctx->aux2_stream, ctx->ev_fork, 0));
 	for (int k = 0; k < kExtBins; ++k) {
 		const int b = order[k];
-		ctx->stream = b >= 3 ? ctx->aux_stream : b < 2 && sched == 2 ? ctx->aux_stream : b < 2 && sched == 3 ? ctx->aux2_stream : main_s; // the launchers enqueue on ctx->stream
+		ctx->stream = b >= 3 ? ctx->aux_stream : b < 2 && (sched == 2 || sched == 4) ? ctx->aux_stream : b < 2 && sched == 3 ? ctx->aux2_stream : main_s; // the launchers enqueue on ctx->stream
 		if (tm) {
 			rc = (int)hipEventRecord(ctx->ev_bin[b], ctx->stream);
 			if (rc) { ctx->stream = main_s; return set_hip_error(ctx, (hipError_t)rc, "hipEventRecord"); }
