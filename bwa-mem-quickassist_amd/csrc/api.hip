@@ -189,6 +189,8 @@ int bmh_ctx_create(bmh_ctx_t **out, int device)
 			return BMH_E_NODEVICE;
 		}
 	ctx->stream = ctx->own_stream;
+	if (const char *m = getenv("BMH_EXT_SMALL")) ctx->small_batch = atoi(m) >= 0 ? atoi(m) : ctx->small_batch;
+	if (getenv("BMH_EXT_MODE")) ctx->ext_mode_forced = true;
 	if (const char *m = getenv("BMH_EXT_MODE")) ctx->force_kernel = !strcmp(m, "lds") ? 1 : !strcmp(m, "reg") ? 2 : !strcmp(m, "grp") ? 3 : !strcmp(m, "lanex4") ? 4 : 0;
 	if (const char *m = getenv("BMH_GLB_MODE")) ctx->glb_mode = !strcmp(m, "wave") ? 1 : 0;
 	if (const char *m = getenv("BMH_SW_MODE")) ctx->sw_mode = !strcmp(m, "generic") ? 1 : 0;

@@ -34,6 +34,8 @@ struct bmh_ctx {
 	DevBuf d_bins; // per-launch bin lists of the extension dispatcher: 4 counters + 4 x n task indices
 	int grid_mult = 1;    // env BMH_GRID_MULT: persistent grid = resident waves x this (tuning knob)
 	int ext_sched = -1;   // env BMH_EXT_SCHED: launch order / streams of the extension bins, -1 = by query length (see launch_extend)
+	bool ext_mode_forced = false; // BMH_EXT_MODE was given
+	int small_batch = 49152;      // batches of at most this many extension tasks go to the one-task-per-wave kernels (env BMH_EXT_SMALL, 0 = never)
 	int force_kernel = 0; // kernels for qlen<=128: 0 lane-per-task, 1 LDS kernel, 2 one task/wave, 3 four tasks/wave (env BMH_EXT_MODE=lds|reg|grp)
 	bool pool_resident = false; // d_pool holds a pool uploaded by bmh_upload_pool()
 	size_t pool_bytes = 0;

@@ -148,7 +148,12 @@ int launch_extend(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_t
 {
 	if (n <= 0) return BMH_OK;
 	int rc;
-	const int mode = ctx->force_kernel; // 0 lane-per-task, 1 lds, 2 reg (1 task/wave), 3 grp (4 tasks/wave)
+	// 0 lane-per-task, 1 lds, 2 reg (1 task/wave), 3 grp (4 tasks/wave).  The lane-per-task kernels are built for
+	// throughput: a wave walks ~100 rows x 128 columns for its 64 tasks, about half a millisecond however small the batch.
+	// A driver round of a few thousand tasks (bmh_chain2aln_batch: 8 192 reads per call) cannot fill the chip anyway and
+	// wants latency: one task per wave finishes in tens of microseconds (8 153 tasks: 0.76 -> 0.26 ms per call, 32 647:
+	// 0.84 -> 0.51 ms; level at 65 k).
+	const int mode = ctx->ext_mode_forced ? ctx->force_kernel : n <= ctx->small_batch ? 2 : 0;
 	const size_t N = (size_t)n;
 	uint32_t *counts, *lists;
 	if ((rc = sort_tasks_begin(ctx, n, &counts, &lists))) return rc;

@@ -52,6 +52,17 @@ static void *prewarm_thread(void *arg)
 	bmh_pool_prewarm(e && atoi(e) > 0 ? atoi(e) : 8);
 	return 0;
 }
+/* A run shorter than the pre-warming (a few hundred reads) must not reach the runtime's teardown with that thread still
+ * inside a HIP call: it is told to stop and waited for. */
+static pthread_t g_prewarm;
+static int g_prewarm_on;
+static void qa_shim_exit(void)
+{
+	if (!g_prewarm_on) return;
+	g_prewarm_on = 0;
+	bmh_pool_stop();
+	pthread_join(g_prewarm, 0);
+}
 __attribute__((constructor)) static void qa_shim_loaded(void)
 {
 	const char *e = getenv("BMH_PREWARM"), *pl = getenv("LD_PRELOAD");
@@ -75,7 +86,10 @@ __attribute__((constructor)) static void qa_shim_loaded(void)
 			if (!strcmp(buf + i, "mem")) { is_mem = 1; break; }
 		if (!is_mem) return;
 	}
-	if (pthread_create(&t, 0, prewarm_thread, 0) == 0) pthread_detach(t);
+	if (pthread_create(&t, 0, prewarm_thread, 0) == 0) {
+		g_prewarm = t, g_prewarm_on = 1;
+		atexit(qa_shim_exit); /* registered after the HIP runtime's own handlers, so it runs before them */
+	}
 }
 
 typedef struct { /* mem_opt_t of the fork, bwamem.h:21-48 */

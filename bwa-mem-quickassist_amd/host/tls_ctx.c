@@ -61,11 +61,14 @@ void bmh_pool_put(bmh_ctx_t *ctx)
 /* Create `n` idle contexts ahead of use (called from a background thread while the host program is still loading its
  * index): context creation costs tens of milliseconds each and contends inside the runtime when many threads do it at
  * once in the middle of the first chunk. */
+static volatile int g_stop; /* the process is going down: stop creating contexts (see bmh_pool_stop) */
+void bmh_pool_stop(void) { g_stop = 1; }
+
 void bmh_pool_prewarm(int n)
 {
 	const char *dev = getenv("BMH_DEVICE");
 	int k;
-	for (k = 0; k < n; ++k) {
+	for (k = 0; k < n && !g_stop; ++k) {
 		bmh_ctx_t *ctx = 0;
 		slot_t *s = 0;
 		if (bmh_ctx_create(&ctx, dev ? atoi(dev) : 0)) return; /* no GPU: the first real call will say so loudly */

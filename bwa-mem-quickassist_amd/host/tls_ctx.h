@@ -12,5 +12,6 @@
 bmh_ctx_t *bmh_pool_get(const bmh_params_t *p);
 void bmh_pool_put(bmh_ctx_t *ctx);
 void bmh_pool_prewarm(int n);
+void bmh_pool_stop(void); /* makes a running bmh_pool_prewarm return after the context it is creating */
 void bmh_tls_die(const char *msg, int code);
 #endif

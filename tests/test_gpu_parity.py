@@ -16,9 +16,12 @@ def pkg():
     return load_package()
 
 
-@pytest.fixture(scope="module")
-def ctx(pkg):
-    c = pkg.Context(0, kswlib.make_params())
+# Small batches (what these tests send) go to the one-task-per-wave kernels by default; "lane" keeps them on the
+# lane-per-task kernels that serve the large batches of the bench, so both production paths see every case below.
+@pytest.fixture(scope="module", params=["auto", "lane"])
+def ctx(pkg, request):
+    from test_kernel_families_gpu import _ctx_with
+    c = _ctx_with({"BMH_EXT_SMALL": "0"} if request.param == "lane" else {})
     yield c
     c.close()
 
