@@ -17,6 +17,28 @@ static slot_t g_slots[BMH_POOL_MAX];
 static int g_n;
 static pthread_mutex_t g_mu = PTHREAD_MUTEX_INITIALIZER;
 
+/* The GPUs the pool's contexts live on: $BMH_DEVICES = comma-separated ordinals (contexts are created on them in turn, so
+ * the host threads' batches spread over the GPUs of a node; the resident reference and index are copied once per device),
+ * else $BMH_DEVICE, else 0. */
+static int pool_device(int nth)
+{
+	const char *list = getenv("BMH_DEVICES"), *one = getenv("BMH_DEVICE");
+	int dev[64], n = 0;
+	if (list && *list) {
+		const char *p = list;
+		while (*p && n < 64) {
+			char *end;
+			long v = strtol(p, &end, 10);
+			if (end == p) break;
+			dev[n++] = (int)v;
+			p = *end == ',' ? end + 1 : end;
+			if (*end != ',') break;
+		}
+	}
+	if (n == 0) return one ? atoi(one) : 0;
+	return dev[nth % n];
+}
+
 void bmh_tls_die(const char *msg, int code)
 {
 	fprintf(stderr, "[bwamem_hip] fatal: %s (%s)\n", msg ? msg : "?", bmh_strerror(code));
@@ -39,8 +61,7 @@ bmh_ctx_t *bmh_pool_get(const bmh_params_t *p)
 	s->busy = 1;
 	pthread_mutex_unlock(&g_mu);
 	if (!s->ctx) {
-		const char *dev = getenv("BMH_DEVICE");
-		if ((rc = bmh_ctx_create(&s->ctx, dev ? atoi(dev) : 0))) bmh_tls_die("cannot create a GPU context", rc);
+		if ((rc = bmh_ctx_create(&s->ctx, pool_device((int)(s - g_slots))))) bmh_tls_die("cannot create a GPU context", rc);
 	}
 	if (!s->have || memcmp(&s->params, p, sizeof(*p)) != 0) {
 		if ((rc = bmh_ctx_set_params(s->ctx, p))) bmh_tls_die(bmh_last_error(s->ctx), rc);
@@ -66,12 +87,11 @@ void bmh_pool_stop(void) { g_stop = 1; }
 
 void bmh_pool_prewarm(int n)
 {
-	const char *dev = getenv("BMH_DEVICE");
 	int k;
 	for (k = 0; k < n && !g_stop; ++k) {
 		bmh_ctx_t *ctx = 0;
 		slot_t *s = 0;
-		if (bmh_ctx_create(&ctx, dev ? atoi(dev) : 0)) return; /* no GPU: the first real call will say so loudly */
+		if (bmh_ctx_create(&ctx, pool_device(k))) return; /* no GPU: the first real call will say so loudly */
 		(void)bmh_ctx_reserve_staging(ctx, (size_t)8 << 20, (size_t)32 << 20); /* what a phase-1 batch of 8 192 reads moves */
 		pthread_mutex_lock(&g_mu);
 		if (g_n < BMH_POOL_MAX) s = &g_slots[g_n++], s->ctx = ctx, s->have = 0, s->busy = 0;

@@ -68,11 +68,12 @@ def genome():
     return rng, tmp, fa, ref
 
 
-def _run(fa, fqs, out, extra, preload):
+def _run(fa, fqs, out, extra, preload, more_env=None):
     env = dict(os.environ)
     if preload:
         env["LD_PRELOAD"] = load_package().DROPIN_PATH
         env["BMH_VERBOSE"] = "1"
+        env.update(more_env or {})
     with open(out, "w") as f:
         r = subprocess.run([reflib.REF_BWA, "mem", "-v", "1"] + extra + [fa] + fqs, stdout=f, stderr=subprocess.PIPE,
                            env=env, timeout=600)
@@ -198,3 +199,17 @@ def test_pe_option_matrix_sam_identical(genome, extra):
     ref_sam = _run(fa, [f1, f2], os.path.join(tmp, "ref_om.sam"), extra, False)
     dut_sam = _run(fa, [f1, f2], os.path.join(tmp, "dut_om.sam"), extra, True)
     assert len(ref_sam) >= 800 and ref_sam == dut_sam
+
+
+def test_pe_sam_identical_with_a_device_list(genome):
+    """$BMH_DEVICES spreads the shim's contexts over several GPUs (each gets its own resident reference and index).  The
+    box has one GPU, so the list names it twice: the contexts alternate between two entries that happen to be one device."""
+    rng, tmp, fa, ref = genome
+    r1, r2 = _sim_reads(rng, ref, 600, 150, False, pair=True, rescue=0.3)
+    fq1, fq2 = os.path.join(tmp, "dl_1.fq"), os.path.join(tmp, "dl_2.fq")
+    reflib.write_fastq(fq1, r1, "p")
+    reflib.write_fastq(fq2, r2, "p")
+    extra = ["-t", "4", "-b", "256"]
+    ref_sam = _run(fa, [fq1, fq2], os.path.join(tmp, "ref_dl.sam"), extra, False)
+    dut_sam = _run(fa, [fq1, fq2], os.path.join(tmp, "dut_dl.sam"), extra, True, {"BMH_DEVICES": "0,0"})
+    assert len(ref_sam) >= 1200 and ref_sam == dut_sam
