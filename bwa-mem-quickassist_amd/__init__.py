@@ -107,6 +107,7 @@ def lib():
         L.bmh_ctx_set_params.argtypes = [C.c_void_p, C.c_void_p]
         L.bmh_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.bmh_ctx_set_qcap.argtypes = [C.c_void_p, C.c_int]
+        L.bmh_ctx_reserve_staging.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t]
         L.bmh_ctx_set_pac.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
         L.bmh_set_kernel_timing.argtypes = [C.c_void_p, C.c_int]
         L.bmh_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
@@ -190,6 +191,10 @@ class Context:
 
     def set_qcap(self, q):
         self._check(lib().bmh_ctx_set_qcap(self._h, int(q)))
+
+    def reserve_staging(self, upload_bytes, download_bytes):
+        """Pinned staging buffers of the host-buffer entry points, allocated ahead of the first batch."""
+        self._check(lib().bmh_ctx_reserve_staging(self._h, int(upload_bytes), int(download_bytes)))
 
     def sync(self):
         self._check(lib().bmh_ctx_sync(self._h))

@@ -132,3 +132,18 @@ def test_global_fuzz_param_sets(ctx):
     for p in kswgen.fuzz_param_sets(rng, 25):
         pool, tasks, words = kswgen.gen_glb_fuzz(rng, 200)
         _cmp_glb(ctx, p, pool, tasks, words)
+
+
+def test_staged_and_direct_transfers_agree(pkg):
+    """Host buffers of up to 64 MB per direction go through the context's pinned staging buffers, larger ones the direct way
+    (csrc/api.hip, Stager): the same batch must come back identical either way, and with staging reserved ahead of time."""
+    rng = np.random.default_rng(207)
+    p = kswlib.make_params()
+    pool, tasks = kswgen.gen_ext_realistic(rng, 3000)
+    want, _ = kswlib.orc_extend_batch(p, pool, tasks)
+    c = pkg.Context(0, p)
+    c.reserve_staging(1 << 20, 1 << 20)
+    assert (c.extend_batch(pool, tasks) == want).all()                       # staged
+    big = np.concatenate([pool, np.zeros(80 << 20, np.uint8)])             # > 64 MB up: not staged
+    assert (c.extend_batch(big, tasks) == want).all()
+    c.close()
