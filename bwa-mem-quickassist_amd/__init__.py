@@ -29,6 +29,10 @@ EXT_TASK = np.dtype([("q_off", "<u8"), ("t_off", "<u8"), ("qlen", "<u2"), ("tlen
                      ("rsv", "<u2")])
 EXT_RES = np.dtype([("score", "<i4"), ("qle", "<i4"), ("tle", "<i4"), ("gtle", "<i4"),
                     ("gscore", "<i4"), ("max_off", "<i4")])
+SEED_TASK = np.dtype([("q_off", "<u8"), ("t_off", "<u8"), ("l_query", "<i4"), ("qbeg", "<i4"), ("len", "<i4"),
+                      ("rbeg", "<i4"), ("wlen", "<i4"), ("flags", "<u2"), ("rsv", "<u2")])
+SEED_RES = np.dtype([("qb", "<i4"), ("qe", "<i4"), ("rb", "<i4"), ("re", "<i4"), ("score", "<i4"), ("truesc", "<i4"),
+                     ("w", "<i4"), ("n_ext", "<i4")])
 GLB_TASK = np.dtype([("q_off", "<u8"), ("t_off", "<u8"), ("qlen", "<u2"), ("tlen", "<u2"),
                      ("w", "<i4"), ("cigar_off", "<u4"), ("cigar_cap", "<u4")])
 GLB_RES = np.dtype([("score", "<i4"), ("n_cigar", "<i4")])
@@ -85,7 +89,7 @@ class _Read(C.Structure):
 
 
 class _DriverStats(C.Structure):
-    _fields_ = [(n, C.c_int64) for n in ("rounds", "ext_tasks", "seeds_extended", "seeds_skipped", "pool_bytes")]
+    _fields_ = [(n, C.c_int64) for n in ("rounds", "ext_tasks", "seeds_extended", "seeds_skipped", "pool_bytes", "seeds_speculated")]
 
 
 _lib = None
@@ -112,9 +116,15 @@ def lib():
         L.bmh_set_kernel_timing.argtypes = [C.c_void_p, C.c_int]
         L.bmh_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.bmh_last_extend_bin_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.bmh_last_global_bin_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.bmh_upload_pool.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.bmh_extend_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int64, C.c_void_p]
         L.bmh_extend_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        L.bmh_seedext_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int64, C.c_void_p]
+        L.bmh_seedext_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.bmh_seedext_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.bmh_seedext_wait.argtypes = [C.c_void_p, C.c_void_p]
+        L.bmh_seedext_stats.argtypes = [C.c_void_p, C.c_void_p]
         L.bmh_ctx_set_bwt.argtypes = [C.c_void_p, C.c_void_p]
         L.bmh_smem_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                      C.c_void_p, C.c_size_t]
@@ -212,6 +222,11 @@ class Context:
         self._check(lib().bmh_last_extend_bin_ms(self._h, ms))
         return [float(x) for x in ms]
 
+    def last_global_bin_ms(self):
+        ms = (C.c_float * 3)()
+        self._check(lib().bmh_last_global_bin_ms(self._h, ms))
+        return [float(x) for x in ms]
+
     # ---- L2, host buffers
     def extend_batch(self, pool, tasks):
         """N x ksw_extend2 (reference ksw.c:379).  numpy in, numpy out."""
@@ -220,6 +235,23 @@ class Context:
         res = np.zeros(len(tasks), dtype=EXT_RES)
         self._check(lib().bmh_extend_batch(self._h, _ptr(pool), pool.nbytes, _ptr(tasks), len(tasks), _ptr(res)))
         return res
+
+    def seedext_batch(self, pool, tasks):
+        """N x (left extension, clip decision, right extension from the left score): the fused per-seed record
+        (reference bwamem.c:810-866; ext_param_t / ext_res_t :553-577).  numpy in, numpy out."""
+        pool = np.ascontiguousarray(pool, dtype=np.uint8)
+        tasks = np.ascontiguousarray(tasks, dtype=SEED_TASK)
+        res = np.zeros(len(tasks), dtype=SEED_RES)
+        self._check(lib().bmh_seedext_batch(self._h, _ptr(pool), pool.nbytes, _ptr(tasks), len(tasks), _ptr(res)))
+        return res
+
+    def seedext_batch_device(self, d_pool, d_tasks, n, d_res):
+        self._check(lib().bmh_seedext_batch_device(self._h, C.c_void_p(d_pool), C.c_void_p(d_tasks), int(n), C.c_void_p(d_res)))
+
+    def seedext_stats(self):
+        st = (C.c_int64 * 5)()
+        self._check(lib().bmh_seedext_stats(self._h, st))
+        return dict(zip(("seeds", "left_tasks", "left_retries", "right_tasks", "right_retries"), [int(x) for x in st]))
 
     def global_batch(self, pool, tasks, cigar_words):
         """N x ksw_global2 (reference ksw.c:501).  Returns (results, cigar_pool)."""

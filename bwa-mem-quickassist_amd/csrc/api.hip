@@ -188,7 +188,16 @@ int bmh_ctx_create(bmh_ctx_t **out, int device)
 			bmh_ctx_destroy(ctx);
 			return BMH_E_NODEVICE;
 		}
+	for (int b = 0; b < 4; ++b)
+		if (hipEventCreate(&ctx->ev_gbin[b]) != hipSuccess) {
+			bmh_ctx_destroy(ctx);
+			return BMH_E_NODEVICE;
+		}
 	ctx->stream = ctx->own_stream;
+	(void)hipDeviceGetAttribute(&ctx->ncu, hipDeviceAttributeMultiprocessorCount, device);
+	if (ctx->ncu <= 0) ctx->ncu = 256;
+	if (const char *m = getenv("BMH_EXT_PERSIST")) ctx->ext_persist = atoi(m) != 0;
+	if (const char *m = getenv("BMH_EXT_GRID_MULT")) ctx->ext_grid_mult = atoi(m) > 0 ? atoi(m) : ctx->ext_grid_mult;
 	if (const char *m = getenv("BMH_EXT_SMALL")) ctx->small_batch = atoi(m) >= 0 ? atoi(m) : ctx->small_batch;
 	if (getenv("BMH_EXT_MODE")) ctx->ext_mode_forced = true;
 	if (const char *m = getenv("BMH_EXT_MODE")) ctx->force_kernel = !strcmp(m, "lds") ? 1 : !strcmp(m, "reg") ? 2 : !strcmp(m, "grp") ? 3 : !strcmp(m, "lanex4") ? 4 : 0;
@@ -210,6 +219,11 @@ int bmh_ctx_destroy(bmh_ctx_t *ctx)
 	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 	free_buf(ctx->d_pool), free_buf(ctx->d_tasks), free_buf(ctx->d_res), free_buf(ctx->d_order);
 	free_buf(ctx->d_cigar), free_buf(ctx->d_scratch), free_buf(ctx->d_bins), free_buf(ctx->d_zslab), free_buf(ctx->d_sw), free_buf(ctx->d_swrm);
+	free_buf(ctx->d_seedws);
+	for (auto &h : ctx->hint) {
+		if (h.ev) (void)hipEventDestroy(h.ev);
+		if (h.h) (void)hipHostFree(h.h);
+	}
 	pac_release(ctx);
 	if (ctx->bwt_bind) free_bwt_binding(ctx->bwt_bind);
 	if (ctx->d_err) (void)hipFree(ctx->d_err);
@@ -223,6 +237,8 @@ int bmh_ctx_destroy(bmh_ctx_t *ctx)
 		if (ctx->ev_bin[b]) (void)hipEventDestroy(ctx->ev_bin[b]);
 		if (ctx->ev_bin_end[b]) (void)hipEventDestroy(ctx->ev_bin_end[b]);
 	}
+	for (int b = 0; b < 4; ++b)
+		if (ctx->ev_gbin[b]) (void)hipEventDestroy(ctx->ev_gbin[b]);
 	if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
 	if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
 	if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
@@ -373,6 +389,16 @@ int bmh_last_extend_bin_ms(bmh_ctx_t *ctx, float ms[6])
 	return BMH_OK;
 }
 
+int bmh_last_global_bin_ms(bmh_ctx_t *ctx, float ms[3])
+{
+	if (!ctx || !ms) return BMH_E_ARG;
+	ms[0] = ms[1] = ms[2] = -1.f;
+	if (!ctx->ev_gbin_valid) return BMH_OK;
+	BMH_HIP(ctx, hipEventSynchronize(ctx->ev_gbin[3]));
+	for (int b = 0; b < 3; ++b) BMH_HIP(ctx, hipEventElapsedTime(&ms[b], ctx->ev_gbin[b], ctx->ev_gbin[b + 1]));
+	return BMH_OK;
+}
+
 // ------------------------------------------------------------------ extend
 
 int bmh_extend_batch_device(bmh_ctx_t *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
@@ -508,6 +534,109 @@ int bmh_extend_batch_sharded(bmh_ctx_t *const *ctxs, int n_ctx, const uint8_t *p
 		if (rc && !first) first = rc;
 	}
 	return first;
+}
+
+// ------------------------------------------------------------------ fused per-seed extension (row a5)
+
+int bmh_seedext_batch_device(bmh_ctx_t *ctx, const uint8_t *d_pool, const bmh_seed_task_t *d_tasks, int64_t n,
+                             bmh_seed_result_t *d_res)
+{
+	if (!ctx || n < 0 || (n > 0 && (!d_pool || !d_tasks || !d_res))) return BMH_E_ARG;
+	if (!ctx->have_params) return BMH_E_ARG;
+	if (n > 0x7fffffffLL) return BMH_E_ARG;
+	BMH_HIP(ctx, hipSetDevice(ctx->device));
+	return launch_seedext(ctx, d_pool, d_tasks, n, d_res, ctx->qcap);
+}
+
+static int validate_seeds(bmh_ctx *ctx, const bmh_seed_task_t *t, int64_t n, size_t pool_bytes, int *qmax)
+{
+	int qm = 1;
+	const int smax = std::max(ctx->dev.max_mat, ctx->params.a);
+	for (int64_t k = 0; k < n; ++k) {
+		const bmh_seed_task_t &x = t[k];
+		const int64_t rq = (int64_t)x.l_query - x.qbeg - x.len, rt = (int64_t)x.wlen - x.rbeg - x.len;
+		const bool tp = x.flags & BMH_F_TPAC;
+		if (tp && !ctx->dev.pac) {
+			ctx->last_error = "seed " + std::to_string(k) + " has BMH_F_TPAC but no reference was uploaded (bmh_ctx_set_pac)";
+			return BMH_E_ARG;
+		}
+		if (x.l_query < 1 || x.qbeg < 0 || x.len < 1 || rq < 0 || x.rbeg < 0 || rt < 0 || x.wlen < 0) {
+			ctx->last_error = "seed " + std::to_string(k) + " does not lie inside its read and window";
+			return BMH_E_ARG;
+		}
+		const uint64_t tspace = tp ? (uint64_t)(ctx->dev.l_pac << 1) : (uint64_t)pool_bytes;
+		if (x.q_off + (uint64_t)x.l_query > pool_bytes || x.t_off + (uint64_t)x.wlen > tspace) {
+			ctx->last_error = "seed " + std::to_string(k) + " reads outside the sequence pool";
+			return BMH_E_ARG;
+		}
+		if (x.qbeg > 65535 || rq > 65535 || x.rbeg > 65535 || rt > 65535 || (int64_t)x.l_query * smax > kScoreLimit) {
+			ctx->last_error = "seed " + std::to_string(k) + ": flank longer than 65535 or scores beyond the 16-bit range";
+			return BMH_E_RANGE;
+		}
+		qm = std::max(qm, std::max(x.qbeg, (int)rq));
+	}
+	*qmax = qm;
+	return BMH_OK;
+}
+
+int bmh_seedext_submit(bmh_ctx_t *ctx, const bmh_seed_task_t *tasks, int64_t n)
+{
+	if (!ctx || n < 0 || (n > 0 && !tasks)) return BMH_E_ARG;
+	if (!ctx->have_params || !ctx->pool_resident || ctx->seed_pending_n >= 0) return BMH_E_ARG;
+	if (n > 0x7fffffffLL) return BMH_E_ARG;
+	int qmax = 1, rc;
+	if ((rc = validate_seeds(ctx, tasks, n, ctx->pool_bytes, &qmax))) return rc;
+	BMH_HIP(ctx, hipSetDevice(ctx->device));
+	const size_t tb = (size_t)n * sizeof(bmh_seed_task_t), rb = (size_t)n * sizeof(bmh_seed_result_t);
+	if ((rc = ensure(ctx, ctx->d_tasks, tb + 64)) || (rc = ensure(ctx, ctx->d_res, rb + 64))) return rc;
+	if ((rc = ensure_host(ctx, ctx->h_up, tb + 256)) || (rc = ensure_host(ctx, ctx->h_down, rb + 256))) return rc;
+	if (n > 0) {
+		memcpy(ctx->h_up.p, tasks, tb);
+		BMH_HIP(ctx, hipMemcpyAsync(ctx->d_tasks.p, ctx->h_up.p, tb, hipMemcpyHostToDevice, ctx->stream));
+		if ((rc = launch_seedext(ctx, (const uint8_t *)ctx->d_pool.p, (const bmh_seed_task_t *)ctx->d_tasks.p, n,
+		                         (bmh_seed_result_t *)ctx->d_res.p, qmax)))
+			return rc;
+		BMH_HIP(ctx, hipMemcpyAsync(ctx->h_down.p, ctx->d_res.p, rb, hipMemcpyDeviceToHost, ctx->stream));
+		BMH_HIP(ctx, hipMemcpyAsync((uint8_t *)ctx->h_down.p + ((rb + 63) & ~(size_t)63), seedext_counters(ctx), 16, hipMemcpyDeviceToHost,
+		                            ctx->stream));
+	}
+	ctx->seed_pending_n = n;
+	return BMH_OK;
+}
+
+int bmh_seedext_wait(bmh_ctx_t *ctx, bmh_seed_result_t *results)
+{
+	if (!ctx || ctx->seed_pending_n < 0 || (ctx->seed_pending_n > 0 && !results)) return BMH_E_ARG;
+	const int64_t n = ctx->seed_pending_n;
+	ctx->seed_pending_n = -1;
+	if (n == 0) return BMH_OK;
+	BMH_HIP(ctx, hipSetDevice(ctx->device));
+	const int rc = fetch_err(ctx); // synchronises
+	const size_t rb = (size_t)n * sizeof(bmh_seed_result_t);
+	memcpy(results, ctx->h_down.p, rb);
+	const uint32_t *c = (const uint32_t *)((const uint8_t *)ctx->h_down.p + ((rb + 63) & ~(size_t)63));
+	ctx->sstats.seeds = n, ctx->sstats.left_tasks = c[0], ctx->sstats.left_retries = c[1], ctx->sstats.right_tasks = c[2],
+	ctx->sstats.right_retries = c[3];
+	return rc;
+}
+
+int bmh_seedext_batch(bmh_ctx_t *ctx, const uint8_t *pool, size_t pool_bytes, const bmh_seed_task_t *tasks, int64_t n,
+                      bmh_seed_result_t *results)
+{
+	if (!ctx || n < 0 || (n > 0 && (!tasks || !results))) return BMH_E_ARG;
+	if (!ctx->have_params) return BMH_E_ARG;
+	if (n == 0) return BMH_OK;
+	int rc;
+	if (pool && (rc = bmh_upload_pool(ctx, pool, pool_bytes))) return rc;
+	if ((rc = bmh_seedext_submit(ctx, tasks, n))) return rc;
+	return bmh_seedext_wait(ctx, results);
+}
+
+int bmh_seedext_stats(const bmh_ctx_t *ctx, bmh_seedext_stats_t *st)
+{
+	if (!ctx || !st) return BMH_E_ARG;
+	*st = ctx->sstats;
+	return BMH_OK;
 }
 
 // ------------------------------------------------------------------ global

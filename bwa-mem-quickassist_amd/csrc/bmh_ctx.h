@@ -55,8 +55,27 @@ struct bmh_ctx {
 	hipStream_t aux2_stream = nullptr; // ... and the two short-query bins beside the 128-column one
 	hipEvent_t ev_join2 = nullptr;
 	bool ev_bin_valid = false;
+	hipEvent_t ev_gbin[4] = {}; // boundaries of the three kernels of a global-alignment launch (64-slot, 128-slot, wave)
+	bool ev_gbin_valid = false;
 	std::string last_error;
 	bmh_driver_stats_t dstats{};
+	int ncu = 256; // compute units of the device (persistent grids are sized from it)
+	bool ext_persist = false; // extension lane kernels as one strided launch with a capped grid (env BMH_EXT_PERSIST=1)
+	int ext_grid_mult = 2; // extension lane kernels: grid cap = resident waves x this (env BMH_EXT_GRID_MULT)
+	// Bin sizes of the extension dispatcher are only known on the device.  After every launch they are copied to pinned
+	// memory WITHOUT waiting; the next launch of the same kind (plain API call, or stage k of the fused per-seed
+	// pipeline) reads whatever has arrived and sizes its grids / picks the kernel of bin 3 from it.  A stale or missing
+	// hint costs speed, never correctness: every kernel strides over its bin whatever the grid.
+	static constexpr int kHintKinds = 6;
+	struct BinHint {
+		uint32_t *h = nullptr;   // pinned, 16 words: the bins' counts of the launch that wrote it
+		hipEvent_t ev = nullptr; // recorded behind the copy
+		bool pending = false, valid = false;
+		uint32_t cnt[8] = {};
+	} hint[kHintKinds];
+	DevBuf d_seedws; // workspace of the fused per-seed extension (seedext.hip)
+	bmh_seedext_stats_t sstats{};
+	int64_t seed_pending_n = -1; // tasks of the bmh_seedext_submit() in flight, -1 = none
 };
 
 namespace bmh {
@@ -77,13 +96,19 @@ int ensure_host(bmh_ctx *ctx, DevBuf &b, size_t bytes); // same, pinned host mem
 constexpr long long kPersistentGrid = 256LL * 32 * 4;
 
 // dispatcher: classifies the tasks by query length on the device and runs each bin on its kernel
+// d_n (nullable): device-side count <= n of the entries of d_order (or of d_tasks) that are tasks; kind: which
+// BinHint slot the launch reads and refreshes
 int launch_extend(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
-                  bmh_ext_result_t *d_res, const uint32_t *d_order, int qmax);
+                  bmh_ext_result_t *d_res, const uint32_t *d_order, int qmax, const uint32_t *d_n = nullptr, int kind = 0);
+int launch_seedext(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_seed_task_t *d_tasks, int64_t n,
+                   bmh_seed_result_t *d_res, int qmax);
+const uint32_t *seedext_counters(const bmh_ctx *ctx); // the four list lengths of the last launch_seedext, on the device
+inline long long ext_resident_waves(const bmh_ctx *ctx, int waves_per_simd) { return (long long)ctx->ncu * 4 * waves_per_simd; }
 int launch_extend_lds(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
-                      bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, int qmax);
+                      bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, int qmax, long long grid_cap = 0);
 constexpr int kSortKeysHost = 2048; // == kSortKeys in extend_dispatch.hip
 int sort_tasks_begin(bmh_ctx *ctx, int64_t n, uint32_t **counts, uint32_t **lists);
-int sort_tasks_finish(bmh_ctx *ctx, int64_t n, const uint32_t *d_order, unsigned blocks);
+int sort_tasks_finish(bmh_ctx *ctx, int64_t n, const uint32_t *d_order, unsigned blocks, const uint32_t *d_n = nullptr);
 int launch_global_lane(bmh_ctx *ctx, int c, const uint8_t *d_pool, const bmh_glb_task_t *d_tasks, int64_t n,
                        bmh_glb_result_t *d_res, uint32_t *d_cigar, const uint32_t *d_order, const uint32_t *d_count,
                        int rows_cap);
@@ -102,9 +127,9 @@ int launch_sw_lane(bmh_ctx *ctx, int b, bool corr, bool word, const uint8_t *d_p
 int launch_sw_generic(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks, int64_t n,
                       bmh_sw_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, int qcap, int tcap);
 int launch_extend_lane(bmh_ctx *ctx, int c, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
-                       bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count);
+                       bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, bool exact);
 int launch_extend_reg(bmh_ctx *ctx, int ns, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
-                      bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, int max_count = 0);
+                      bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, int max_count = 0, long long grid_cap = 0);
 int launch_global(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_glb_task_t *d_tasks, int64_t n,
                   bmh_glb_result_t *d_res, uint32_t *d_cigar, const uint32_t *d_order, int qmax, int tmax,
                   int wmax);

@@ -13,6 +13,8 @@
 // The bins are built ON THE DEVICE (a counting sort by bin and expected row count), and every
 // extension kernel reads its bin size from device memory, so a launch needs no
 // host round trip and the *_device entry point stays asynchronous on the caller's stream.
+#include <algorithm>
+
 #include "bmh_ctx.h"
 #include "bmh_device.h"
 
@@ -41,7 +43,7 @@ __device__ __forceinline__ int ext_sort_key(int bin, int qlen, int tlen, int h0)
 	const int rows = min(tlen, 2 * qlen + 8) >> (bin > 2 ? bin - 2 : 0);
 	// h0 decides how wide the live interval is (cells stay non-zero within ~h0-o-e of the diagonal), so lanes
 	// with a similar h0 need the same 8-column blocks
-	return (((qlen - qlo) >> qsh) * 8 + min(max(h0, 0) >> 4, 7)) * 16 + min(rows >> 4, 15);
+	return ((max(qlen - qlo, 0) >> qsh) * 8 + min(max(h0, 0) >> 4, 7)) * 16 + min(rows >> 4, 15);
 }
 
 constexpr int kSortBlocks = 512, kSortThreads = 256;
@@ -51,11 +53,13 @@ constexpr int kLanexMinTasks = 4096; // below this many 129-256 bp flanks one wa
 __global__ __launch_bounds__(kSortThreads) void sort_hist_kernel(const bmh_ext_task_t *__restrict__ tasks,
                                                                  const uint32_t *__restrict__ order, long long n,
                                                                  uint32_t *__restrict__ hist,
-                                                                 uint16_t *__restrict__ binkey, int mode)
+                                                                 uint16_t *__restrict__ binkey, int mode,
+                                                                 const uint32_t *__restrict__ dn)
 {
 	__shared__ uint32_t lh[kSortBins * kSortKeys];
 	for (int t = threadIdx.x; t < kSortBins * kSortKeys; t += kSortThreads) lh[t] = 0;
 	__syncthreads();
+	if (dn) n = min(n, (long long)*dn); // the list was built on the device (fused per-seed pipeline)
 	const long long chunk = (n + gridDim.x - 1) / gridDim.x, lo = chunk * blockIdx.x, hi = min(lo + chunk, n);
 	for (long long k = lo + threadIdx.x; k < hi; k += kSortThreads) {
 		const uint32_t idx = order ? order[k] : (uint32_t)k;
@@ -99,11 +103,13 @@ __global__ __launch_bounds__(1024) void sort_scan_kernel(uint32_t *__restrict__ 
 __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint32_t *__restrict__ order, long long n,
                                                                     uint32_t *__restrict__ cursor,
                                                                     const uint16_t *__restrict__ binkey,
-                                                                    uint32_t *__restrict__ lists)
+                                                                    uint32_t *__restrict__ lists, long long stride,
+                                                                    const uint32_t *__restrict__ dn)
 {
 	__shared__ uint32_t lh[kSortBins * kSortKeys];
 	for (int t = threadIdx.x; t < kSortBins * kSortKeys; t += kSortThreads) lh[t] = 0;
 	__syncthreads();
+	if (dn) n = min(n, (long long)*dn);
 	const long long chunk = (n + gridDim.x - 1) / gridDim.x, lo = chunk * blockIdx.x, hi = min(lo + chunk, n);
 	for (long long k = lo + threadIdx.x; k < hi; k += kSortThreads) atomicAdd(&lh[binkey[k]], 1u);
 	__syncthreads();
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(kSortThreads) void sort_scatter_kernel(const uint32
 	for (long long k = lo + threadIdx.x; k < hi; k += kSortThreads) {
 		const uint32_t bk = binkey[k];
 		const uint32_t pos = atomicAdd(&lh[bk], 1u);
-		lists[(size_t)(bk / kSortKeys) * (size_t)n + pos] = order ? order[k] : (uint32_t)k;
+		lists[(size_t)(bk / kSortKeys) * (size_t)stride + pos] = order ? order[k] : (uint32_t)k;
 	}
 }
 
@@ -130,7 +136,7 @@ int sort_tasks_begin(bmh_ctx *ctx, int64_t n, uint32_t **counts, uint32_t **list
 	return BMH_OK;
 }
 
-int sort_tasks_finish(bmh_ctx *ctx, int64_t n, const uint32_t *d_order, unsigned blocks)
+int sort_tasks_finish(bmh_ctx *ctx, int64_t n, const uint32_t *d_order, unsigned blocks, const uint32_t *d_n)
 {
 	const size_t N = (size_t)n, hist_words = (size_t)kSortBins * kSortKeys;
 	uint32_t *counts = (uint32_t *)ctx->d_bins.p, *hist = counts + 16;
@@ -138,32 +144,71 @@ int sort_tasks_finish(bmh_ctx *ctx, int64_t n, const uint32_t *d_order, unsigned
 	uint32_t *lists = hist + hist_words + (N + 1) / 2 + 1;
 	hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(1024), 0, ctx->stream, hist, counts);
 	hipLaunchKernelGGL(sort_scatter_kernel, dim3(blocks), dim3(kSortThreads), 0, ctx->stream, d_order, (long long)n, hist, binkey,
-	                   lists);
+	                   lists, (long long)n, d_n);
 	BMH_HIP(ctx, hipGetLastError());
 	return BMH_OK;
 }
 
+// ---- bin-size hints (bmh_ctx::BinHint): the counts of the previous launch of the same kind, if they have arrived
+static void hint_poll(bmh_ctx *ctx, int kind)
+{
+	bmh_ctx::BinHint &h = ctx->hint[kind];
+	if (h.pending && hipEventQuery(h.ev) == hipSuccess) {
+		for (int b = 0; b < 8; ++b) h.cnt[b] = h.h[b];
+		h.pending = false, h.valid = true;
+	}
+}
+
+static int hint_post(bmh_ctx *ctx, int kind, const uint32_t *d_counts)
+{
+	bmh_ctx::BinHint &h = ctx->hint[kind];
+	if (h.pending) return BMH_OK; // the previous copy has not landed yet; do not overwrite what it is writing
+	if (!h.h) {
+		if (hipHostMalloc((void **)&h.h, 64, hipHostMallocDefault) != hipSuccess || hipEventCreateWithFlags(&h.ev, hipEventDisableTiming) != hipSuccess) {
+			(void)hipGetLastError();
+			return BMH_OK; // no hints then
+		}
+	}
+	BMH_HIP(ctx, hipMemcpyAsync(h.h, d_counts, 32, hipMemcpyDeviceToHost, ctx->stream));
+	BMH_HIP(ctx, hipEventRecord(h.ev, ctx->stream));
+	h.pending = true;
+	return BMH_OK;
+}
+
 int launch_extend(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
-                  bmh_ext_result_t *d_res, const uint32_t *d_order, int qmax)
+                  bmh_ext_result_t *d_res, const uint32_t *d_order, int qmax, const uint32_t *d_n, int kind)
 {
 	if (n <= 0) return BMH_OK;
 	int rc;
+	if (kind < 0 || kind >= bmh_ctx::kHintKinds) kind = 0;
+	hint_poll(ctx, kind);
+	const bmh_ctx::BinHint &hint = ctx->hint[kind];
+	// expected size of bin b: the previous launch's count with a margin -- or, with no hint, the whole batch
+	int64_t est[kExtBins], est_total = 0;
+	for (int b = 0; b < kExtBins; ++b) {
+		est[b] = hint.valid ? std::min<int64_t>(n, (int64_t)hint.cnt[b] + (hint.cnt[b] >> 4) + 64) : n;
+		est_total += hint.valid ? hint.cnt[b] : 0;
+	}
+	if (!hint.valid) est_total = n;
 	// 0 lane-per-task, 1 lds, 2 reg (1 task/wave), 3 grp (4 tasks/wave).  The lane-per-task kernels are built for
 	// throughput: a wave walks ~100 rows x 128 columns for its 64 tasks, about half a millisecond however small the batch.
 	// A driver round of a few thousand tasks (bmh_chain2aln_batch: 8 192 reads per call) cannot fill the chip anyway and
 	// wants latency: one task per wave finishes in tens of microseconds (8 153 tasks: 0.76 -> 0.26 ms per call, 32 647:
-	// 0.84 -> 0.51 ms; level at 65 k).
-	const int mode = ctx->ext_mode_forced ? ctx->force_kernel : n <= ctx->small_batch ? 2 : 0;
+	// 0.84 -> 0.51 ms; level at 65 k).  With a device-side count (d_n) the decision uses the hinted size.
+	const int64_t n_eff = d_n ? std::min<int64_t>(n, est_total + (est_total >> 2) + 64) : n;
+	const int mode = ctx->ext_mode_forced ? ctx->force_kernel : n_eff <= ctx->small_batch ? 2 : 0;
 	const size_t N = (size_t)n;
 	uint32_t *counts, *lists;
 	if ((rc = sort_tasks_begin(ctx, n, &counts, &lists))) return rc;
 	uint32_t *hist = counts + 16;
 	uint16_t *binkey = (uint16_t *)(hist + (size_t)kSortBins * kSortKeys);
-	long long cg = (n + 1023) / 1024;
+	long long cg = (n_eff + 1023) / 1024;
 	if (cg > kSortBlocks) cg = kSortBlocks;
+	if (cg < 1) cg = 1;
 	hipLaunchKernelGGL(sort_hist_kernel, dim3((unsigned)cg), dim3(kSortThreads), 0, ctx->stream, d_tasks, d_order, (long long)n,
-	                   hist, binkey, mode);
-	if ((rc = sort_tasks_finish(ctx, n, d_order, (unsigned)cg))) return rc;
+	                   hist, binkey, mode, d_n);
+	if ((rc = sort_tasks_finish(ctx, n, d_order, (unsigned)cg, d_n))) return rc;
+	if ((rc = hint_post(ctx, kind, counts))) return rc;
 	const bool tm = ctx->timing;
 	if (tm) BMH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
 	// Bins 0-2 (lane-per-task kernels, almost all tasks) run on the caller's stream; the few long flanks of bins 3-5
@@ -190,20 +235,31 @@ int launch_extend(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_t
 		}
 		const uint32_t *lst = lists + (size_t)b * N, *cnt = counts + b;
 		const int qlo = b == 0 ? 0 : 16 << b; // bins 0..4 hold qlen <= 32,64,128,256,512
+		// grid of the bin's kernel: sized for the expected count (every kernel strides over its bin, so any grid is
+		// correct); a bin the hint calls empty still gets a few hundred waves in case the batch differs from the last one
+		const int64_t eb = std::max<int64_t>(est[b], 16384);
 		rc = BMH_OK;
-		if (b < 5 && (mode == 1 || qmax <= qlo)) {
+		if (b < 5 && (mode == 1 || (qmax <= qlo && !(mode == 3 && b == 3)))) { // (mode 3 routes long targets of short queries to bin 3)
 			// provably empty bin
 		} else if (b <= 2) {
-			if (mode == 0 || mode == 4) rc = launch_extend_lane(ctx, 32 << b, d_pool, d_tasks, n, d_res, lst, cnt);
+			if (mode == 0 || mode == 4) rc = launch_extend_lane(ctx, 32 << b, d_pool, d_tasks, hint.valid ? est[b] : n, d_res, lst, cnt, !hint.valid);
 			else if (mode == 3) rc = launch_extend_grp(ctx, 2 << b, d_pool, d_tasks, n, d_res, lst, cnt);
-			else rc = launch_extend_reg(ctx, b == 2 ? 2 : 1, d_pool, d_tasks, n, d_res, lst, cnt);
+			else rc = launch_extend_reg(ctx, b == 2 ? 2 : 1, d_pool, d_tasks, n, d_res, lst, cnt, 0, est[b]);
 		} else if (b == 3) {
-			if (mode == 0 || mode == 4) { // both are launched; the bin size (known on the device only) decides which one works
-				rc = launch_extend_lanex(ctx, 2, d_pool, d_tasks, n, d_res, lst, cnt, kLanexMinTasks);
-				if (!rc) rc = launch_extend_reg(ctx, 4, d_pool, d_tasks, n < kLanexMinTasks ? n : kLanexMinTasks, d_res, lst, cnt, kLanexMinTasks);
-			} else rc = launch_extend_reg(ctx, 4, d_pool, d_tasks, n, d_res, lst, cnt);
-		} else if (b == 4 && mode == 4) rc = launch_extend_lanex(ctx, 4, d_pool, d_tasks, n, d_res, lst, cnt, 0);
-		else if (b == 5 || (b == 4 && mode != 4)) rc = b == 5 ? launch_extend_lds(ctx, d_pool, d_tasks, mode != 1 && qmax <= 256 ? 4096 : n, d_res, lst, cnt, qmax) : BMH_OK;
+			if (mode == 0 || mode == 4) {
+				// the bin size (known on the device only) decides which kernel works: many 129-256 bp flanks -> two lanes per
+				// task, a handful -> one wave per task.  With a hint exactly one of them is launched (either handles any count);
+				// without one both are, and each looks at the count
+				if (hint.valid) {
+					if (hint.cnt[3] >= (uint32_t)kLanexMinTasks) rc = launch_extend_lanex(ctx, 2, d_pool, d_tasks, eb, d_res, lst, cnt, 0);
+					else rc = launch_extend_reg(ctx, 4, d_pool, d_tasks, n, d_res, lst, cnt, 0, std::max<int64_t>(est[3], 1024));
+				} else {
+					rc = launch_extend_lanex(ctx, 2, d_pool, d_tasks, n, d_res, lst, cnt, kLanexMinTasks);
+					if (!rc) rc = launch_extend_reg(ctx, 4, d_pool, d_tasks, n < kLanexMinTasks ? n : kLanexMinTasks, d_res, lst, cnt, kLanexMinTasks);
+				}
+			} else rc = launch_extend_reg(ctx, 4, d_pool, d_tasks, n, d_res, lst, cnt, 0, est[b]);
+		} else if (b == 4 && mode == 4) rc = launch_extend_lanex(ctx, 4, d_pool, d_tasks, eb, d_res, lst, cnt, 0);
+		else if (b == 5) rc = launch_extend_lds(ctx, d_pool, d_tasks, n, d_res, lst, cnt, qmax, hint.valid ? std::max<int64_t>(est[5], 512) : (mode != 1 && qmax <= 256 ? 4096 : 0));
 		if (!rc && tm) rc = (int)hipEventRecord(ctx->ev_bin_end[b], ctx->stream) ? BMH_E_HIP : BMH_OK;
 		if (rc) { ctx->stream = main_s; return rc; }
 	}

@@ -21,6 +21,8 @@
 //   * all tasks of a wave start together at row 0, so the row index and the loop are wave-uniform; a lane that
 //     finishes (m==0, z-drop, last row) writes its result and idles until the wave is done.  The dispatcher
 //     hands this kernel tasks SORTED by expected row count, so lanes of a wave finish together.
+#include <algorithm>
+
 #include "bmh_ctx.h"
 #include "bmh_device.h"
 
@@ -43,13 +45,15 @@ constexpr bool kLaneFastBlocks = BMH_LANE_FAST_BLOCKS; // unpredicated body for 
 __device__ __forceinline__ int bfi2(int mask, int a, int b) { return __builtin_amdgcn_bitop3_b32(mask, a, b, 0xca); }
 
 // SYM: o_del+e_del == o_ins+e_ins (bwa's default) -> H-oe is computed once per cell for both gap states
-template <int C, bool SYM>
+// LOOP: the block walks the bin with a grid stride from chunk `chunk0` on (persistent grid; costs the register allocator
+// some per-row scratch traffic at C = 128); !LOOP: one chunk per block, chunk = chunk0 + blockIdx.x.
+template <int C, bool SYM, bool LOOP>
 __global__ __launch_bounds__(64, BMH_LANE_WAVES(C)) void extend_lane_kernel(const uint8_t *__restrict__ pool,
                                                          const bmh_ext_task_t *__restrict__ tasks,
                                                          const uint32_t *__restrict__ order,
                                                          const uint32_t *__restrict__ count, long long n,
                                                          bmh_ext_result_t *__restrict__ out, DevParams P,
-                                                         int *__restrict__ err_flag)
+                                                         int *__restrict__ err_flag, long long chunk0)
 {
 	constexpr int NW = C / 32, NQ = C / 4, NB = C / 8;
 	constexpr int INF = 0x7fff;
@@ -67,8 +71,9 @@ __global__ __launch_bounds__(64, BMH_LANE_WAVES(C)) void extend_lane_kernel(cons
 		srow[lane] = make_uint2(lo, (uint32_t)(uint8_t)mat_at(P, lane * 5 + 4));
 	}
 	const long long cnt = count ? (long long)*count : n;
-	const long long base = (long long)blockIdx.x * 64;
-	if (base >= cnt) return;
+	// persistent grid: a block walks the bin in chunks of 64 tasks with a grid stride (the launcher sizes the grid for
+	// the machine, not for the batch, so an empty or small bin costs a few hundred waves instead of n/64)
+	for (long long base = (chunk0 + (long long)blockIdx.x) * 64; base < cnt; base += LOOP ? (long long)gridDim.x * 64 : cnt) {
 	const bool valid = base + lane < cnt;
 	// the bin list is sorted ascending (short queries / few rows first); walk it from the back so the most
 	// expensive waves are dispatched first and the cheap ones fill the tail
@@ -249,31 +254,44 @@ __global__ __launch_bounds__(64, BMH_LANE_WAVES(C)) void extend_lane_kernel(cons
 			p[3] = gk < 0 ? 0 : (gk & 0xffff) + 1, p[4] = gk < 0 ? -1 : gk >> 16, p[5] = maxoff;
 		}
 	}
+	} // chunk loop
 }
 
-// ---- launcher: tasks listed in d_order[0..*d_count) must have 1 <= qlen <= C
+// ---- launcher: tasks listed in d_order[0..*d_count) must have 1 <= qlen <= C.  `n` is the dispatcher's estimate of the
+// bin size (exact or an upper bound without a hint).  persist: one strided launch with a capped grid.  Otherwise one
+// chunk per block over the estimate, plus a small strided launch that picks up whatever lies beyond it.
 int launch_extend_lane(bmh_ctx *ctx, int c, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
-                       bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count)
+                       bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, bool exact)
 {
 	if (n <= 0) return BMH_OK;
-	const long long grid = (n + 63) / 64; // blocks past the bin's device-side count return at once
 	const bool sym = ctx->dev.o_del + ctx->dev.e_del == ctx->dev.o_ins + ctx->dev.e_ins;
-#define BMH_LAUNCH_LANE(CC)                                                                                             \
+	const long long chunks = (n + 63) / 64;
+	const long long cap = ext_resident_waves(ctx, BMH_LANE_WAVES(c)) * ctx->ext_grid_mult;
+#define BMH_LAUNCH_LANE2(CC, SY, LP, GRID, C0)                                                                          \
+	hipLaunchKernelGGL((extend_lane_kernel<CC, SY, LP>), dim3((unsigned)(GRID)), dim3(64), 0, ctx->stream, d_pool, d_tasks,  \
+	                   d_order, d_count, (long long)n, d_res, ctx->dev, ctx->d_err, (long long)(C0))
+#define BMH_LAUNCH_LANE(CC, LP, GRID, C0)                                                                               \
 	do {                                                                                                                \
-		if (sym)                                                                                                        \
-			hipLaunchKernelGGL((extend_lane_kernel<CC, true>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_pool,  \
-			                   d_tasks, d_order, d_count, (long long)n, d_res, ctx->dev, ctx->d_err);                 \
-		else                                                                                                            \
-			hipLaunchKernelGGL((extend_lane_kernel<CC, false>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_pool, \
-			                   d_tasks, d_order, d_count, (long long)n, d_res, ctx->dev, ctx->d_err);                 \
+		if (sym) BMH_LAUNCH_LANE2(CC, true, LP, GRID, C0);                                                              \
+		else BMH_LAUNCH_LANE2(CC, false, LP, GRID, C0);                                                                 \
 	} while (0)
-	switch (c) {
-	case 32: BMH_LAUNCH_LANE(32); break;
-	case 64: BMH_LAUNCH_LANE(64); break;
-	case 128: BMH_LAUNCH_LANE(128); break;
-	default: return BMH_E_ARG;
+#define BMH_LAUNCH_LANE_C(LP, GRID, C0)                                                                                 \
+	do {                                                                                                                \
+		switch (c) {                                                                                                    \
+		case 32: BMH_LAUNCH_LANE(32, LP, GRID, C0); break;                                                              \
+		case 64: BMH_LAUNCH_LANE(64, LP, GRID, C0); break;                                                              \
+		case 128: BMH_LAUNCH_LANE(128, LP, GRID, C0); break;                                                            \
+		default: return BMH_E_ARG;                                                                                      \
+		}                                                                                                               \
+	} while (0)
+	if (ctx->ext_persist) BMH_LAUNCH_LANE_C(true, std::min(chunks, cap), 0);
+	else {
+		BMH_LAUNCH_LANE_C(false, chunks, 0);
+		if (!exact) BMH_LAUNCH_LANE_C(true, 256, chunks); // beyond the estimate: usually nothing
 	}
+#undef BMH_LAUNCH_LANE_C
 #undef BMH_LAUNCH_LANE
+#undef BMH_LAUNCH_LANE2
 	BMH_HIP(ctx, hipGetLastError());
 	return BMH_OK;
 }

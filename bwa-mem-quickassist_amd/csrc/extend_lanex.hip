@@ -60,8 +60,9 @@ __global__ __launch_bounds__(64, 2) void extend_lanex_kernel(const uint8_t *__re
 		srow[lane] = make_uint2(lo, (uint32_t)(uint8_t)mat_at(P, lane * 5 + 4));
 	}
 	const long long cnt = count ? (long long)*count : n;
-	const long long base = (long long)blockIdx.x * TPW;
-	if (base >= cnt || cnt < min_count) return; // a handful of tasks is served better by one wave per task (extend_reg_kernel)
+	if (cnt < min_count) return; // a handful of tasks is served better by one wave per task (extend_reg_kernel)
+	// persistent grid: chunks of TPW tasks, grid stride (see extend_lane_kernel)
+	for (long long base = (long long)blockIdx.x * TPW; base < cnt; base += (long long)gridDim.x * TPW) {
 	const bool valid = base + lane / LPT < cnt;
 	const long long pos = cnt - 1 - (valid ? base + lane / LPT : base); // sorted ascending: expensive waves first
 	const uint32_t idx = order ? order[pos] : (uint32_t)pos;
@@ -213,6 +214,7 @@ __global__ __launch_bounds__(64, 2) void extend_lanex_kernel(const uint8_t *__re
 			if (role == LPT - 1) p[3] = gk < 0 ? 0 : (gk & 0xffff) + 1, p[4] = gk < 0 ? -1 : gk >> 16;
 		}
 	}
+	} // chunk loop
 }
 
 // ---- launcher: tasks listed in d_order[0..*d_count) must have 1 <= qlen <= 128*lpt
@@ -221,7 +223,9 @@ int launch_extend_lanex(bmh_ctx *ctx, int lpt, const uint8_t *d_pool, const bmh_
 {
 	if (n <= 0) return BMH_OK;
 	const int tpw = 64 / lpt;
-	const long long grid = (n + tpw - 1) / tpw; // blocks past the bin's device-side count return at once
+	long long grid = (n + tpw - 1) / tpw; // n = the dispatcher's upper bound of the bin size; the kernel strides
+	const long long cap = ext_resident_waves(ctx, 2) * ctx->ext_grid_mult;
+	if (grid > cap) grid = cap;
 	if (lpt == 2)
 		hipLaunchKernelGGL(extend_lanex_kernel<2>, dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_pool, d_tasks, d_order, d_count,
 		                   (long long)n, d_res, ctx->dev, ctx->d_err, min_count);

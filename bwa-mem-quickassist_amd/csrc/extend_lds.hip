@@ -180,13 +180,14 @@ __global__ __launch_bounds__(64) void extend_lds_kernel(const uint8_t *__restric
 
 // ---- launcher: every task listed in d_order[0..*d_count) (or 0..n when d_count is null)
 int launch_extend_lds(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
-                      bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, int qmax)
+                      bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, int qmax, long long grid_cap)
 {
 	if (n <= 0) return BMH_OK;
 	const int qcap = (qmax + 63) & ~63;
 	const size_t shmem = (((size_t)4 * (qcap + 2) + 15) & ~(size_t)15) + (size_t)8 * qcap + 32;
 	if (shmem > 160 * 1024) return BMH_E_RANGE;
-	const long long grid = n < kPersistentGrid ? n : kPersistentGrid;
+	long long grid = n < kPersistentGrid ? n : kPersistentGrid;
+	if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
 	hipLaunchKernelGGL(extend_lds_kernel, dim3((unsigned)grid), dim3(64), shmem, ctx->stream, d_pool, d_tasks, d_order,
 	                   d_count, (long long)n, d_res, ctx->dev, qcap, ctx->d_err);
 	BMH_HIP(ctx, hipGetLastError());

@@ -237,10 +237,11 @@ __global__ __launch_bounds__(64) void extend_reg_kernel(const uint8_t *__restric
 
 // ---- launcher: every task listed in d_order[0..*d_count) (or 0..n) must have 1 <= qlen <= 64*ns
 int launch_extend_reg(bmh_ctx *ctx, int ns, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
-                      bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, int max_count)
+                      bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, int max_count, long long grid_cap)
 {
 	if (n <= 0) return BMH_OK;
-	const long long grid = n < kPersistentGrid ? n : kPersistentGrid;
+	long long grid = n < kPersistentGrid ? n : kPersistentGrid;
+	if (grid_cap > 0 && grid > grid_cap) grid = grid_cap;
 #define BMH_LAUNCH_REG(NS)                                                                                           \
 	hipLaunchKernelGGL(extend_reg_kernel<NS>, dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_pool, d_tasks, d_order, \
 	                   d_count, (long long)n, d_res, ctx->dev, ctx->d_err, max_count)

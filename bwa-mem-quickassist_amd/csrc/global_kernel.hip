@@ -255,12 +255,16 @@ int launch_global(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_glb_task_t *d_t
 	hipLaunchKernelGGL(glb_sort_hist_kernel, dim3((unsigned)cg), dim3(256), 0, ctx->stream, d_tasks, d_order, (long long)n, hist,
 	                   binkey, ctx->dev, lane_ok ? 1 : 0, rows_cap);
 	if ((rc = sort_tasks_finish(ctx, n, d_order, (unsigned)cg))) return rc;
-	if (ctx->timing) BMH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+	const bool tm = ctx->timing;
+	if (tm) BMH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
 	if (lane_ok) {
+		if (tm) BMH_HIP(ctx, hipEventRecord(ctx->ev_gbin[0], ctx->stream));
 		if ((rc = launch_global_lane(ctx, 64, d_pool, d_tasks, n, d_res, d_cigar, lists, counts + 0, rows_cap))) return rc;
+		if (tm) BMH_HIP(ctx, hipEventRecord(ctx->ev_gbin[1], ctx->stream));
 		if (wmax > 31 && (rc = launch_global_lane(ctx, 128, d_pool, d_tasks, n, d_res, d_cigar, lists + N, counts + 1, rows_cap)))
 			return rc;
 	}
+	if (tm) BMH_HIP(ctx, hipEventRecord(ctx->ev_gbin[2], ctx->stream));
 	{ // bin 2: the wave kernel
 		const uint32_t *lst = lists + 2 * N, *cnt = counts + 2;
 		const int qcap = (qmax + 63) & ~63;
@@ -288,9 +292,10 @@ int launch_global(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_glb_task_t *d_t
 		}
 		BMH_HIP(ctx, hipGetLastError());
 	}
-	if (ctx->timing) {
+	if (tm) {
+		BMH_HIP(ctx, hipEventRecord(ctx->ev_gbin[3], ctx->stream));
 		BMH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-		ctx->ev_valid = true;
+		ctx->ev_valid = true, ctx->ev_gbin_valid = lane_ok;
 	}
 	return BMH_OK;
 }

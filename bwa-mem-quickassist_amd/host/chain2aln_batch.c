@@ -6,17 +6,31 @@
  * the function the fork meant to batch as mem_chain2aln_batched() (bwamem.c:580,
  * commented call at :1110) but never finished.
  *
- * Why a state machine and not "extend everything": inside one read the work is
- * sequential by construction -- the right extension starts from the left score
- * (bwamem.c:842,854), the second band try depends on the first (:828,:856), and
- * whether a seed is extended at all depends on the regions produced by earlier
- * seeds AND earlier chains of the same read (:769-802, shared `av`).  Different
- * reads are independent.  So every read runs the exact control flow of the
- * reference as a resumable state machine that stops whenever it needs a
- * ksw_extend2 result; each ROUND collects one pending extension per unfinished
- * read, runs them as one GPU batch (bmh_extend_batch on the resident sequence
- * pool), and feeds the results back.  Exactly the extensions the reference would
- * run are run -- no speculation, identical output.
+ * Inside one read the work is sequential by construction: the right extension
+ * starts from the left score (bwamem.c:842,854), the second band try depends on
+ * the first (:828,:856), and whether a seed is extended at all depends on the
+ * regions produced by earlier seeds AND earlier chains of the same read
+ * (:769-802, shared `av`).  Different reads are independent.
+ *
+ * The first two dependencies live on the device: bmh_seedext_batch runs a seed's
+ * left extension, retries, clip decision and right extension as ONE record (the
+ * ext_param_t/ext_res_t the fork sketched, bwamem.c:553-577).  The third one is
+ * resolved here with a result cache and (bounded) speculation, which is exact
+ * because a seed's extension is a pure function of the seed and its window:
+ *   round 1  the longest seed of every chain of every read -- the one the
+ *            reference extends first in that chain (bwamem.c:760-765);
+ *   replay   every read runs the reference's exact control flow, taking
+ *            extension results from the cache; a read that needs a result that
+ *            is not there stops;
+ *   round 2  for the stopped reads: the missing seed and every later seed the
+ *            reference could still extend (all but those that are provably
+ *            skipped: contained in a region that already exists, bwamem.c:769-784,
+ *            with no conflicting seed even among the ones that were skipped,
+ *            :788-799 -- regions only accumulate, so "contained" stays true);
+ *   replay   completes every read.  (The loop would go on if a result were still
+ *            missing; by the argument above it is not.)
+ * Output is identical to the reference's; the extensions run are a superset of
+ * the reference's (bmh_driver_stats: seeds_extended vs seeds_speculated).
  *
  * Sequence pool (uploaded once per batch): every read's codes, then one
  * reference window [rmax0,rmax1) per chain (bwamem.c:740-757), decoded on the
@@ -66,18 +80,16 @@ static void fetch_window(int64_t l_pac, const uint8_t *pac, int64_t beg, int64_t
 typedef struct {
 	int64_t rmax0, rmax1;
 	uint64_t win_off; /* pool offset of the window's first base */
+	size_t seed_base; /* index of the chain's seed 0 in the flat result cache */
 } chain_win_t;
 
-enum { ST_NEXT_CHAIN, ST_NEXT_SEED, ST_LEFT_WAIT, ST_RIGHT_WAIT, ST_DONE };
+enum { ST_NEXT_CHAIN, ST_NEXT_SEED, ST_DONE };
 
 typedef struct {
-	int st, ci, k, tri;
-	int aw0, aw1, sc0;
-	size_t ai;          /* index of the region under construction in regs[r].a */
+	int st, ci, k;
 	size_t chain_base;  /* index of this read's first chain in the flat chain_win_t array */
 	uint64_t read_off;  /* pool offset of the read */
 	uint64_t *srt;
-	const bmh_seed_t *s;
 } rstate_t;
 
 static bmh_alnreg_t *regs_push(bmh_alnreg_v *v) /* kv_pushp, kvec.h:82-86 */
@@ -116,17 +128,37 @@ static int seed_near_region(const bmh_params_t *p, const bmh_seed_t *s, const bm
 	return 0;
 }
 
+/* the overlap test of bwamem.c:793-794 */
+static inline int seeds_conflict(const bmh_seed_t *s, const bmh_seed_t *t)
+{
+	if (t->len < s->len * .95) return 0; /* double compare, bwamem.c:792 */
+	if (s->qbeg <= t->qbeg && s->qbeg + s->len - t->qbeg >= s->len >> 2 && t->qbeg - s->qbeg != t->rbeg - s->rbeg) return 1;
+	if (t->qbeg <= s->qbeg && t->qbeg + t->len - s->qbeg >= s->len >> 2 && s->qbeg - t->qbeg != s->rbeg - t->rbeg) return 1;
+	return 0;
+}
+
 /* bwamem.c:788-799: does another, not-skipped, long-enough seed overlap s off-diagonal? */
 static int has_conflicting_seed(const bmh_chain_t *c, const uint64_t *srt, int k, const bmh_seed_t *s)
 {
 	int i;
 	for (i = k + 1; i < c->n; ++i) {
-		const bmh_seed_t *t;
 		if (srt[i] == 0) continue;
-		t = &c->seeds[(uint32_t)srt[i]];
-		if (t->len < s->len * .95) continue;
-		if (s->qbeg <= t->qbeg && s->qbeg + s->len - t->qbeg >= s->len >> 2 && t->qbeg - s->qbeg != t->rbeg - s->rbeg) return 1;
-		if (t->qbeg <= s->qbeg && t->qbeg + t->len - s->qbeg >= s->len >> 2 && s->qbeg - t->qbeg != s->rbeg - t->rbeg) return 1;
+		if (seeds_conflict(s, &c->seeds[(uint32_t)srt[i]])) return 1;
+	}
+	return 0;
+}
+
+/* the same question asked BEFORE the chain's earlier seeds have been decided: every seed that sorts after `si`
+ * (longer, or as long with a larger index) counts, skipped or not -- a superset of the conflicts the reference will see */
+static int may_conflict(const bmh_chain_t *c, int si)
+{
+	const bmh_seed_t *s = &c->seeds[si];
+	const uint64_t key = (uint64_t)s->len << 32 | (uint32_t)si;
+	int i;
+	for (i = 0; i < c->n; ++i) {
+		const uint64_t ki = (uint64_t)c->seeds[i].len << 32 | (uint32_t)i;
+		if (ki <= key || ki == 0) continue;
+		if (seeds_conflict(s, &c->seeds[i])) return 1;
 	}
 	return 0;
 }
@@ -141,83 +173,14 @@ typedef struct {
 	const chain_win_t *wins;
 	int tpac; /* targets come from the device-resident pac */
 	bmh_driver_stats_t st;
-	int err;
+	/* extension results by (chain, seed): 0 = not asked for, 1 = asked for in the round being built, 2 = there */
+	uint8_t *have;
+	bmh_seed_result_t *cache;
 } drv_t;
 
-static int emit_left(drv_t *d, int r, rstate_t *rs, bmh_ext_task_t *t)
-{
-	const chain_win_t *cw = &d->wins[rs->chain_base + (size_t)rs->ci];
-	const bmh_seed_t *s = rs->s;
-	int64_t tl = s->rbeg - cw->rmax0;
-	if (s->qbeg > 65535 || tl > 65535 || tl < 0) return BMH_E_RANGE;
-	rs->aw0 = d->p->w << rs->tri;
-	if (rs->aw0 > 32767) return BMH_E_RANGE;
-	memset(t, 0, sizeof(*t));
-	t->q_off = rs->read_off + (uint64_t)(s->qbeg - 1); /* query[qbeg-1-i], bwamem.c:814 */
-	if (d->tpac) t->t_off = (uint64_t)(tl > 0 ? s->rbeg - 1 : cw->rmax0); /* same bases, read from the resident pac */
-	else t->t_off = cw->win_off + (uint64_t)(tl > 0 ? tl - 1 : 0);       /* rseq[tmp-1-i], bwamem.c:817 */
-	t->qlen = (uint16_t)s->qbeg, t->tlen = (uint16_t)tl;
-	t->h0 = s->len * d->p->a;
-	t->w = (int16_t)rs->aw0, t->end_bonus = (int16_t)d->p->pen_clip5;
-	t->flags = BMH_F_QREV | BMH_F_TREV | (d->tpac ? BMH_F_TPAC : 0);
-	(void)r;
-	return 0;
-}
-
-static int emit_right(drv_t *d, int r, rstate_t *rs, bmh_ext_task_t *t)
-{
-	const chain_win_t *cw = &d->wins[rs->chain_base + (size_t)rs->ci];
-	const bmh_seed_t *s = rs->s;
-	const int l_query = d->reads[r].l_seq, qe = s->qbeg + s->len;
-	const int64_t re = s->rbeg + s->len - cw->rmax0, tl = cw->rmax1 - cw->rmax0 - re;
-	if (l_query - qe > 65535 || tl > 65535 || tl < 0 || re < 0) return BMH_E_RANGE;
-	rs->aw1 = d->p->w << rs->tri;
-	if (rs->aw1 > 32767) return BMH_E_RANGE;
-	memset(t, 0, sizeof(*t));
-	t->q_off = rs->read_off + (uint64_t)qe;
-	t->t_off = d->tpac ? (uint64_t)(cw->rmax0 + re) : cw->win_off + (uint64_t)re;
-	t->flags = d->tpac ? BMH_F_TPAC : 0;
-	t->qlen = (uint16_t)(l_query - qe), t->tlen = (uint16_t)tl;
-	t->h0 = rs->sc0;
-	t->w = (int16_t)rs->aw1, t->end_bonus = (int16_t)d->p->pen_clip3;
-	return 0;
-}
-
-static void finish_seed(drv_t *d, int r, rstate_t *rs)
-{
-	const bmh_chain_t *c = &d->chains[r].a[rs->ci];
-	bmh_alnreg_t *a = &d->regs[r].a[rs->ai];
-	int i;
-	for (i = 0, a->seedcov = 0; i < c->n; ++i) { /* bwamem.c:870-874 */
-		const bmh_seed_t *t = &c->seeds[i];
-		if (t->qbeg >= a->qb && t->qbeg + t->len <= a->qe && t->rbeg >= a->rb && t->rbeg + t->len <= a->re)
-			a->seedcov += t->len;
-	}
-	a->w = imax(rs->aw0, rs->aw1); /* bwamem.c:875 */
-	--rs->k;
-	rs->st = ST_NEXT_SEED;
-}
-
-/* after the left side is known: start the right side or close the region (bwamem.c:841,866) */
-static int begin_right(drv_t *d, int r, rstate_t *rs, bmh_ext_task_t *t)
-{
-	const bmh_seed_t *s = rs->s;
-	bmh_alnreg_t *a = &d->regs[r].a[rs->ai];
-	if (s->qbeg + s->len != d->reads[r].l_seq) {
-		int rc;
-		rs->sc0 = a->score;
-		rs->tri = 0;
-		if ((rc = emit_right(d, r, rs, t))) return rc;
-		rs->st = ST_RIGHT_WAIT;
-		return 1; /* task emitted */
-	}
-	a->qe = d->reads[r].l_seq, a->re = s->rbeg + s->len;
-	finish_seed(d, r, rs);
-	return 0;
-}
-
-/* Runs read r until it needs a GPU result (returns 1 with *t filled) or is done (returns 0); <0 on error. */
-static int advance(drv_t *d, int r, rstate_t *rs, bmh_ext_task_t *t)
+/* Runs read r with the reference's control flow (bwamem.c:1101-1107 over :760-876) for as long as the extension results
+ * it needs are cached.  Returns 0 when the read is finished, 1 when it stopped at a seed whose result is missing. */
+static int run_read(drv_t *d, int r, rstate_t *rs)
 {
 	for (;;) {
 		if (rs->st == ST_NEXT_CHAIN) {
@@ -239,81 +202,72 @@ static int advance(drv_t *d, int r, rstate_t *rs, bmh_ext_task_t *t)
 			rs->st = ST_NEXT_SEED;
 		} else if (rs->st == ST_NEXT_SEED) {
 			const bmh_chain_t *c = &d->chains[r].a[rs->ci];
+			const chain_win_t *cw = &d->wins[rs->chain_base + (size_t)rs->ci];
+			const bmh_seed_t *s;
+			const bmh_seed_result_t *x;
 			bmh_alnreg_t *a;
-			int rc;
+			uint32_t si;
+			int i;
 			if (rs->k < 0) {
 				free(rs->srt);
 				rs->srt = 0;
 				rs->st = ST_NEXT_CHAIN;
 				continue;
 			}
-			rs->s = &c->seeds[(uint32_t)rs->srt[rs->k]];
-			if (seed_near_region(d->p, rs->s, &d->regs[r]) && !has_conflicting_seed(c, rs->srt, rs->k, rs->s)) {
+			si = (uint32_t)rs->srt[rs->k];
+			s = &c->seeds[si];
+			if (seed_near_region(d->p, s, &d->regs[r]) && !has_conflicting_seed(c, rs->srt, rs->k, s)) {
 				rs->srt[rs->k] = 0; /* bwamem.c:796-799 */
 				--rs->k;
 				++d->st.seeds_skipped;
 				continue;
 			}
+			if (d->have[cw->seed_base + si] != 2) return 1; /* the device has not extended this seed yet */
 			++d->st.seeds_extended;
+			x = &d->cache[cw->seed_base + si];
 			a = regs_push(&d->regs[r]); /* bwamem.c:804-807 */
-			rs->ai = d->regs[r].n - 1;
 			memset(a, 0, sizeof(*a));
-			a->w = rs->aw0 = rs->aw1 = d->p->w;
-			a->score = a->truesc = -1;
-			if (rs->s->qbeg) { /* bwamem.c:810 */
-				rs->tri = 0;
-				if ((rc = emit_left(d, r, rs, t))) return rc;
-				rs->st = ST_LEFT_WAIT;
-				return 1;
+			a->qb = x->qb, a->qe = x->qe, a->rb = cw->rmax0 + x->rb, a->re = cw->rmax0 + x->re; /* bwamem.c:831-866 */
+			a->score = x->score, a->truesc = x->truesc, a->w = x->w;                          /* ... and :875 */
+			for (i = 0, a->seedcov = 0; i < c->n; ++i) { /* bwamem.c:870-874 */
+				const bmh_seed_t *t = &c->seeds[i];
+				if (t->qbeg >= a->qb && t->qbeg + t->len <= a->qe && t->rbeg >= a->rb && t->rbeg + t->len <= a->re)
+					a->seedcov += t->len;
 			}
-			a->score = a->truesc = rs->s->len * d->p->a, a->qb = 0, a->rb = rs->s->rbeg; /* bwamem.c:839 */
-			if ((rc = begin_right(d, r, rs, t)) != 0) return rc;
-		} else return rs->st == ST_DONE ? 0 : BMH_E_ARG;
+			--rs->k;
+		} else return 0;
 	}
 }
 
-/* Feeds one extension result to read r; returns 1 if it immediately needs another (same seed), 0 otherwise. */
-static int deliver(drv_t *d, int r, rstate_t *rs, const bmh_ext_result_t *x, bmh_ext_task_t *t)
+typedef struct {
+	bmh_seed_task_t *t;
+	size_t *slot; /* cache slot of each task */
+	size_t n, m;
+} req_t;
+
+static int request(drv_t *d, req_t *q, int r, const rstate_t *rs, int ci, int si)
 {
-	bmh_alnreg_t *a = &d->regs[r].a[rs->ai];
-	const bmh_seed_t *s = rs->s;
-	const int prev = a->score;
-	int rc;
-	a->score = x->score;
-	if (rs->st == ST_LEFT_WAIT) {
-		const int aw = rs->aw0;
-		if (!(a->score == prev || x->max_off < (aw >> 1) + (aw >> 2)) && rs->tri + 1 < MAX_BAND_TRY) { /* bwamem.c:828 */
-			++rs->tri;
-			if ((rc = emit_left(d, r, rs, t))) return rc;
-			return 1;
-		}
-		if (x->gscore <= 0 || x->gscore <= a->score - d->p->pen_clip5) { /* bwamem.c:831-837 */
-			a->qb = s->qbeg - x->qle, a->rb = s->rbeg - x->tle;
-			a->truesc = a->score;
-		} else {
-			a->qb = 0, a->rb = s->rbeg - x->gtle;
-			a->truesc = x->gscore;
-		}
-		return begin_right(d, r, rs, t);
-	} else { /* ST_RIGHT_WAIT */
-		const chain_win_t *cw = &d->wins[rs->chain_base + (size_t)rs->ci];
-		const int aw = rs->aw1, qe = s->qbeg + s->len;
-		const int64_t re = s->rbeg + s->len - cw->rmax0;
-		if (!(a->score == prev || x->max_off < (aw >> 1) + (aw >> 2)) && rs->tri + 1 < MAX_BAND_TRY) { /* bwamem.c:856 */
-			++rs->tri;
-			if ((rc = emit_right(d, r, rs, t))) return rc;
-			return 1;
-		}
-		if (x->gscore <= 0 || x->gscore <= a->score - d->p->pen_clip3) { /* bwamem.c:859-865 */
-			a->qe = qe + x->qle, a->re = cw->rmax0 + re + x->tle;
-			a->truesc += a->score - rs->sc0;
-		} else {
-			a->qe = d->reads[r].l_seq, a->re = cw->rmax0 + re + x->gtle;
-			a->truesc += x->gscore - rs->sc0;
-		}
-		finish_seed(d, r, rs);
-		return 0;
+	const chain_win_t *cw = &d->wins[rs->chain_base + (size_t)ci];
+	const bmh_seed_t *s = &d->chains[r].a[ci].seeds[si];
+	bmh_seed_task_t *t;
+	if (d->have[cw->seed_base + (size_t)si]) return 0;
+	if (q->n == q->m) {
+		q->m = q->m ? q->m << 1 : 1024;
+		q->t = (bmh_seed_task_t *)realloc(q->t, sizeof(*q->t) * q->m);
+		q->slot = (size_t *)realloc(q->slot, sizeof(*q->slot) * q->m);
+		if (!q->t || !q->slot) return BMH_E_NOMEM;
 	}
+	if (s->rbeg < cw->rmax0 || s->rbeg + s->len > cw->rmax1 || cw->rmax1 - cw->rmax0 > 0x7fffffff) return BMH_E_RANGE;
+	t = &q->t[q->n];
+	memset(t, 0, sizeof(*t));
+	t->q_off = rs->read_off;
+	t->t_off = d->tpac ? (uint64_t)cw->rmax0 : cw->win_off; /* rseq[0], bwamem.c:757 */
+	t->flags = d->tpac ? BMH_F_TPAC : 0;
+	t->l_query = d->reads[r].l_seq, t->qbeg = s->qbeg, t->len = s->len;
+	t->rbeg = (int32_t)(s->rbeg - cw->rmax0), t->wlen = (int32_t)(cw->rmax1 - cw->rmax0);
+	q->slot[q->n++] = cw->seed_base + (size_t)si;
+	d->have[cw->seed_base + (size_t)si] = 1;
+	return 0;
 }
 
 static double now_s(void)
@@ -332,14 +286,15 @@ int bmh_chain2aln_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n
 	rstate_t *rs = 0;
 	chain_win_t *wins = 0;
 	uint8_t *pool = 0;
-	bmh_ext_task_t *tasks = 0;
-	bmh_ext_result_t *res = 0;
-	int *owner = 0;
-	size_t n_chains = 0, pool_bytes = 0, ci_flat;
-	int r, rc = BMH_OK, n_tasks;
+	bmh_seed_result_t *res = 0;
+	int *stopped = 0;
+	req_t q;
+	size_t n_chains = 0, n_seeds = 0, pool_bytes = 0, ci_flat;
+	int r, rc = BMH_OK, n_stopped;
 
 	if (!ctx || n_reads < 0 || (n_reads > 0 && (!reads || !chains || !regs || !pac))) return BMH_E_ARG;
 	memset(&d, 0, sizeof(d));
+	memset(&q, 0, sizeof(q));
 	d.p = bmh_ctx_params_(ctx);
 	if (!d.p) return BMH_E_ARG;
 	if (n_reads == 0) return BMH_OK;
@@ -350,7 +305,8 @@ int bmh_chain2aln_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n
 	rs = (rstate_t *)calloc((size_t)n_reads, sizeof(rstate_t));
 	for (r = 0; r < n_reads; ++r) n_chains += chains[r].n;
 	wins = (chain_win_t *)calloc(n_chains + 1, sizeof(chain_win_t));
-	if (!rs || !wins) { rc = BMH_E_NOMEM; goto done; }
+	stopped = (int *)malloc(sizeof(int) * (size_t)n_reads);
+	if (!rs || !wins || !stopped) { rc = BMH_E_NOMEM; goto done; }
 	for (r = 0, ci_flat = 0; r < n_reads; ++r) {
 		size_t ci;
 		rs[r].read_off = pool_bytes, rs[r].chain_base = ci_flat, rs[r].ci = -1, rs[r].st = ST_NEXT_CHAIN;
@@ -360,7 +316,9 @@ int bmh_chain2aln_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n
 			chain_win_t *cw = &wins[ci_flat];
 			const int l_query = reads[r].l_seq;
 			int i;
-			if (c->n == 0) continue;
+			cw->seed_base = n_seeds;
+			if (c->n <= 0) continue;
+			n_seeds += (size_t)c->n;
 			cw->rmax0 = l_pac << 1, cw->rmax1 = 0;
 			for (i = 0; i < c->n; ++i) {
 				const bmh_seed_t *t = &c->seeds[i];
@@ -390,10 +348,9 @@ int bmh_chain2aln_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n
 
 	/* pass 2: fill and upload the pool once */
 	pool = (uint8_t *)malloc(pool_bytes + 16);
-	tasks = (bmh_ext_task_t *)malloc(sizeof(bmh_ext_task_t) * (size_t)n_reads);
-	res = (bmh_ext_result_t *)malloc(sizeof(bmh_ext_result_t) * (size_t)n_reads);
-	owner = (int *)malloc(sizeof(int) * (size_t)n_reads);
-	if (!pool || !tasks || !res || !owner) { rc = BMH_E_NOMEM; goto done; }
+	d.have = (uint8_t *)calloc(n_seeds + 1, 1);
+	d.cache = (bmh_seed_result_t *)malloc(sizeof(bmh_seed_result_t) * (n_seeds + 1));
+	if (!pool || !d.have || !d.cache) { rc = BMH_E_NOMEM; goto done; }
 	for (r = 0; r < n_reads; ++r) memcpy(pool + rs[r].read_off, reads[r].seq, (size_t)reads[r].l_seq);
 	for (ci_flat = 0; ci_flat < n_chains && !d.tpac; ++ci_flat)
 		if (wins[ci_flat].rmax1 > wins[ci_flat].rmax0)
@@ -401,39 +358,78 @@ int bmh_chain2aln_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n
 	memset(pool + pool_bytes, 0, 16);
 	d.st.pool_bytes = (int64_t)pool_bytes + 16;
 	if ((rc = bmh_upload_pool(ctx, pool, pool_bytes + 16))) goto done;
-
-	/* rounds */
 	t_trace[1] = trace ? now_s() : 0;
-	n_tasks = 0;
+
+	/* round 1: the seed each chain is extended from first -- the last one in (len, index) order, bwamem.c:760-765 */
 	for (r = 0; r < n_reads; ++r) {
-		int k = advance(&d, r, &rs[r], &tasks[n_tasks]);
-		if (k < 0) { rc = k; goto done; }
-		if (k) owner[n_tasks++] = r;
-	}
-	while (n_tasks > 0) {
-		int i, m = 0;
-		++d.st.rounds;
-		d.st.ext_tasks += n_tasks;
-		t_trace[3] = trace ? now_s() : 0;
-		if ((rc = bmh_extend_batch(ctx, 0, 0, tasks, n_tasks, res))) goto done;
-		if (trace) t_trace[2] += now_s() - t_trace[3];
-		for (i = 0; i < n_tasks; ++i) { /* compact in place: slot m <= i is free once task i is consumed */
-			bmh_ext_task_t nt;
-			int k;
-			r = owner[i];
-			k = deliver(&d, r, &rs[r], &res[i], &nt);
-			if (k == 0) k = advance(&d, r, &rs[r], &nt);
-			if (k < 0) { rc = k; goto done; }
-			if (k) tasks[m] = nt, owner[m++] = r;
+		size_t ci;
+		stopped[r] = r;
+		for (ci = 0; ci < chains[r].n; ++ci) {
+			const bmh_chain_t *c = &chains[r].a[ci];
+			int i, top = 0;
+			if (c->n <= 0) continue;
+			for (i = 1; i < c->n; ++i)
+				if (c->seeds[i].len >= c->seeds[top].len) top = i;
+			if ((rc = request(&d, &q, r, &rs[r], (int)ci, top))) goto done;
 		}
-		n_tasks = m;
 	}
+	n_stopped = n_reads;
+	for (;;) {
+		bmh_seedext_stats_t ss;
+		size_t j;
+		int m = 0, i;
+		if (q.n) {
+			++d.st.rounds;
+			t_trace[3] = trace ? now_s() : 0;
+			res = (bmh_seed_result_t *)realloc(res, sizeof(*res) * q.n);
+			if (!res) { rc = BMH_E_NOMEM; goto done; }
+			if ((rc = bmh_seedext_batch(ctx, 0, 0, q.t, (int64_t)q.n, res))) goto done;
+			if (trace) t_trace[2] += now_s() - t_trace[3];
+			bmh_seedext_stats(ctx, &ss);
+			d.st.ext_tasks += ss.left_tasks + ss.left_retries + ss.right_tasks + ss.right_retries;
+			d.st.seeds_speculated += (int64_t)q.n;
+			for (j = 0; j < q.n; ++j) d.cache[q.slot[j]] = res[j], d.have[q.slot[j]] = 2;
+			q.n = 0;
+		}
+		/* replay: every unfinished read goes on until it is done or needs a seed that has not been extended */
+		for (i = 0; i < n_stopped; ++i) {
+			int k;
+			r = stopped[i];
+			k = run_read(&d, r, &rs[r]);
+			if (k == 0) continue;
+			stopped[m++] = r;
+			{ /* what this read may still need: the seed it stopped at, the rest of its chain, the later chains */
+				const bmh_chain_t *c = &chains[r].a[rs[r].ci];
+				size_t ci;
+				int kk;
+				if ((rc = request(&d, &q, r, &rs[r], rs[r].ci, (int)(uint32_t)rs[r].srt[rs[r].k]))) goto done;
+				for (kk = rs[r].k - 1; kk >= 0; --kk) {
+					const int si = (int)(uint32_t)rs[r].srt[kk];
+					if (seed_near_region(d.p, &c->seeds[si], &regs[r]) && !may_conflict(c, si)) continue; /* provably skipped */
+					if ((rc = request(&d, &q, r, &rs[r], rs[r].ci, si))) goto done;
+				}
+				for (ci = (size_t)rs[r].ci + 1; ci < chains[r].n; ++ci) {
+					const bmh_chain_t *c2 = &chains[r].a[ci];
+					int si;
+					for (si = 0; si < c2->n; ++si) {
+						if (seed_near_region(d.p, &c2->seeds[si], &regs[r]) && !may_conflict(c2, si)) continue;
+						if ((rc = request(&d, &q, r, &rs[r], (int)ci, si))) goto done;
+					}
+				}
+			}
+		}
+		n_stopped = m;
+		if (n_stopped == 0) break;
+		if (q.n == 0) { rc = BMH_E_ARG; goto done; } /* cannot happen: a stopped read always asks for its seed */
+	}
+	d.st.seeds_speculated -= d.st.seeds_extended; /* extended on the device but never used */
 	if (trace)
-		fprintf(stderr, "[bwamem_hip] bmh_chain2aln_batch %d reads: windows+pool+upload %.1f ms, %lld rounds: GPU calls %.1f ms, state machine %.1f ms\n",
-		        n_reads, (t_trace[1] - t_trace[0]) * 1e3, (long long)d.st.rounds, t_trace[2] * 1e3, (now_s() - t_trace[1] - t_trace[2]) * 1e3);
+		fprintf(stderr, "[bwamem_hip] bmh_chain2aln_batch %d reads: windows+pool+upload %.1f ms, %lld rounds: GPU calls %.1f ms, replay %.1f ms; %lld seeds extended, %lld speculated in vain\n",
+		        n_reads, (t_trace[1] - t_trace[0]) * 1e3, (long long)d.st.rounds, t_trace[2] * 1e3, (now_s() - t_trace[1] - t_trace[2]) * 1e3,
+		        (long long)d.st.seeds_extended, (long long)d.st.seeds_speculated);
 done:
 	if (rs) for (r = 0; r < n_reads; ++r) free(rs[r].srt);
 	bmh_ctx_set_driver_stats_(ctx, &d.st);
-	free(rs), free(wins), free(pool), free(tasks), free(res), free(owner);
+	free(rs), free(wins), free(pool), free(res), free(stopped), free(q.t), free(q.slot), free(d.have), free(d.cache);
 	return rc;
 }

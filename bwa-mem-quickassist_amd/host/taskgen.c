@@ -61,6 +61,59 @@ size_t bmh_taskgen_pool_bound(const bmh_taskgen_cfg_t *c, const bmh_params_t *p)
 	return (size_t)c->len_max * 4 + (size_t)p->w * 4 + 64;
 }
 
+/* One simulated read: window `ref[0..R)`, read `rd[0..*L)`, clean-copy map `rpos`, the longest seed and the chain window
+ * [rmax0,rmax1) over all seeds (bwamem.c:740-751).  Returns 0 for a read that yields no seed (no extension work). */
+typedef struct {
+	int L, best_q, best_len, best_r;
+	int64_t rmax0, rmax1;
+} sim_read_t;
+
+static int sim_read(const bmh_taskgen_cfg_t *cfg, const bmh_params_t *p, uint64_t *sp, int G, int R, uint8_t *ref, uint8_t *rd,
+                    int *rpos, sim_read_t *o)
+{
+	uint64_t s = *sp;
+	const int L = irand(&s, cfg->len_min, cfg->len_max);
+	int i, x, n = 0, best_q = -1, best_len = 0, best_r = -1, run_q = 0, run_len = 0;
+	int chim_at = (cfg->p_chimera > 0 && urand(&s) < cfg->p_chimera && L > 40) ? irand(&s, 20, L - 1) : L + 1;
+	int64_t rmax0 = 1 << 30, rmax1 = 0;
+	for (i = 0; i < R; ++i) ref[i] = (uint8_t)(splitmix(&s) & 3);
+	/* read = ref[G ...] with errors */
+	for (x = G; n < L && x < R - 1;) {
+		const double u = urand(&s);
+		if (n >= chim_at) { rd[n] = (uint8_t)(splitmix(&s) & 3), rpos[n] = -1, ++n, ++x; continue; }
+		if (u < cfg->p_sub) rd[n] = (uint8_t)((ref[x] + 1 + splitmix(&s) % 3) & 3), rpos[n] = -1, ++n, ++x;
+		else if (u < cfg->p_sub + cfg->p_ins) {
+			int k = irand(&s, 1, cfg->max_indel);
+			for (; k > 0 && n < L; --k) rd[n] = (uint8_t)(splitmix(&s) & 3), rpos[n] = -1, ++n;
+		} else if (u < cfg->p_sub + cfg->p_ins + cfg->p_del) x += irand(&s, 1, cfg->max_indel);
+		else rd[n] = ref[x], rpos[n] = x, ++n, ++x;
+	}
+	if (n < L) { *sp = s; return 0; }
+	if (cfg->p_n > 0)
+		for (i = 0; i < L; ++i)
+			if (urand(&s) < cfg->p_n) rd[i] = 4, rpos[i] = -1;
+	*sp = s;
+	/* seeds = maximal clean diagonal runs >= min_seed_len; chain window over all of them */
+	for (i = 0; i <= L; ++i) {
+		const int cont = i < L && rpos[i] >= 0 && run_len > 0 && rpos[i] == rpos[i - 1] + 1;
+		if (cont) { ++run_len; continue; }
+		if (run_len >= cfg->min_seed_len) {
+			const int qb = run_q, rb = rpos[run_q], rest = L - qb - run_len;
+			const int64_t b = rb - (qb + cal_max_gap(p, qb)), e = rb + run_len + (rest + cal_max_gap(p, rest));
+			if (b < rmax0) rmax0 = b;
+			if (e > rmax1) rmax1 = e;
+			if (run_len > best_len) best_len = run_len, best_q = qb, best_r = rb;
+		}
+		if (i < L && rpos[i] >= 0) run_q = i, run_len = 1;
+		else run_len = 0;
+	}
+	if (best_len == 0) return 0; /* unseeded read: no extension work */
+	if (rmax0 < 0) rmax0 = 0;
+	if (rmax1 > R) rmax1 = R;
+	o->L = L, o->best_q = best_q, o->best_len = best_len, o->best_r = best_r, o->rmax0 = rmax0, o->rmax1 = rmax1;
+	return 1;
+}
+
 /* Generates tasks for reads [0,n_reads).  Returns the number of tasks, or -1 if a
  * capacity is too small.  task_read (nullable) receives the read index of each task. */
 int64_t bmh_taskgen_ext(const bmh_taskgen_cfg_t *cfg, const bmh_params_t *p, int64_t n_reads, uint8_t *pool,
@@ -77,81 +130,87 @@ int64_t bmh_taskgen_ext(const bmh_taskgen_cfg_t *cfg, const bmh_params_t *p, int
 	uint64_t s = cfg->seed;
 
 	for (r = 0; r < n_reads; ++r) {
-		const int L = irand(&s, cfg->len_min, cfg->len_max);
-		int i, x, n = 0, best_q = -1, best_len = 0, best_r = -1, run_q = 0, run_len = 0;
-		int chim_at = (cfg->p_chimera > 0 && urand(&s) < cfg->p_chimera && L > 40) ? irand(&s, 20, L - 1) : L + 1;
-		int64_t rmax0 = 1 << 30, rmax1 = 0;
-		for (i = 0; i < R; ++i) ref[i] = (uint8_t)(splitmix(&s) & 3);
-		/* read = ref[G ...] with errors */
-		for (x = G; n < L && x < R - 1;) {
-			const double u = urand(&s);
-			if (n >= chim_at) { rd[n] = (uint8_t)(splitmix(&s) & 3), rpos[n] = -1, ++n, ++x; continue; }
-			if (u < cfg->p_sub) rd[n] = (uint8_t)((ref[x] + 1 + splitmix(&s) % 3) & 3), rpos[n] = -1, ++n, ++x;
-			else if (u < cfg->p_sub + cfg->p_ins) {
-				int k = irand(&s, 1, cfg->max_indel);
-				for (; k > 0 && n < L; --k) rd[n] = (uint8_t)(splitmix(&s) & 3), rpos[n] = -1, ++n;
-			} else if (u < cfg->p_sub + cfg->p_ins + cfg->p_del) x += irand(&s, 1, cfg->max_indel);
-			else rd[n] = ref[x], rpos[n] = x, ++n, ++x;
-		}
-		if (n < L) continue;
-		if (cfg->p_n > 0)
-			for (i = 0; i < L; ++i)
-				if (urand(&s) < cfg->p_n) rd[i] = 4, rpos[i] = -1;
-		/* seeds = maximal clean diagonal runs >= min_seed_len; chain window over all of them */
-		for (i = 0; i <= L; ++i) {
-			const int cont = i < L && rpos[i] >= 0 && run_len > 0 && rpos[i] == rpos[i - 1] + 1;
-			if (cont) { ++run_len; continue; }
-			if (run_len >= cfg->min_seed_len) {
-				const int qb = run_q, rb = rpos[run_q], rest = L - qb - run_len;
-				const int64_t b = rb - (qb + cal_max_gap(p, qb)), e = rb + run_len + (rest + cal_max_gap(p, rest));
-				if (b < rmax0) rmax0 = b;
-				if (e > rmax1) rmax1 = e;
-				if (run_len > best_len) best_len = run_len, best_q = qb, best_r = rb;
+		sim_read_t o;
+		int i;
+		if (!sim_read(cfg, p, &s, G, R, ref, rd, rpos, &o)) continue;
+		{
+			const int L = o.L, best_q = o.best_q, best_len = o.best_len, best_r = o.best_r;
+			const int64_t rmax0 = o.rmax0, rmax1 = o.rmax1;
+			if (used + (size_t)L + (size_t)(rmax1 - rmax0) + 16 > pool_cap || nt + 2 > task_cap) {
+				nt = -1;
+				break;
 			}
-			if (i < L && rpos[i] >= 0) run_q = i, run_len = 1;
-			else run_len = 0;
+			{
+				const uint64_t read_off = used, win_off = used + (uint64_t)L;
+				int lsc = best_len * p->a;
+				memcpy(pool + read_off, rd, (size_t)L);
+				memcpy(pool + win_off, ref + rmax0, (size_t)(rmax1 - rmax0));
+				used += (size_t)L + (size_t)(rmax1 - rmax0);
+				if (best_q > 0) { /* left extension */
+					bmh_ext_task_t *t = &tasks[nt];
+					const int tl = (int)(best_r - rmax0);
+					int sc = 0, bestsc = 0;
+					memset(t, 0, sizeof(*t));
+					t->q_off = read_off + (uint64_t)(best_q - 1), t->t_off = win_off + (uint64_t)(tl > 0 ? tl - 1 : 0);
+					t->qlen = (uint16_t)best_q, t->tlen = (uint16_t)tl, t->h0 = best_len * p->a;
+					t->w = (int16_t)p->w, t->end_bonus = (int16_t)p->pen_clip5, t->flags = BMH_F_QREV | BMH_F_TREV;
+					if (task_read) task_read[nt] = (uint32_t)r;
+					++nt;
+					for (i = best_q - 1; i >= 0; --i) { /* crude score of the true left alignment, for the right h0 */
+						sc += rpos[i] >= 0 ? p->a : -4;
+						if (sc > bestsc) bestsc = sc;
+					}
+					lsc += bestsc;
+				}
+				if (best_q + best_len < L) { /* right extension */
+					bmh_ext_task_t *t = &tasks[nt];
+					const int qe = best_q + best_len;
+					const int64_t re = best_r + best_len - rmax0;
+					memset(t, 0, sizeof(*t));
+					t->q_off = read_off + (uint64_t)qe, t->t_off = win_off + (uint64_t)re;
+					t->qlen = (uint16_t)(L - qe), t->tlen = (uint16_t)(rmax1 - rmax0 - re), t->h0 = lsc;
+					t->w = (int16_t)p->w, t->end_bonus = (int16_t)p->pen_clip3;
+					if (task_read) task_read[nt] = (uint32_t)r;
+					++nt;
+				}
+			}
 		}
-		if (best_len == 0) continue; /* unseeded read: no extension work */
-		if (rmax0 < 0) rmax0 = 0;
-		if (rmax1 > R) rmax1 = R;
-		if (used + (size_t)L + (size_t)(rmax1 - rmax0) + 16 > pool_cap || nt + 2 > task_cap) {
+	}
+	free(ref), free(rd), free(rpos);
+	if (pool_used) *pool_used = used;
+	return nt;
+}
+
+/* The same simulated reads as ONE fused record per read (bmh_seed_task_t: the longest seed of the read's chain with its
+ * window) -- what the per-seed extension entry point consumes: the right extension then starts from the score the
+ * device computed for the left one (bwamem.c:842,854), not from a guess.  One task per seeded read; the read and its
+ * window lie back to back in the pool.  Returns the number of tasks, -1 if a capacity is too small. */
+int64_t bmh_taskgen_seed(const bmh_taskgen_cfg_t *cfg, const bmh_params_t *p, int64_t n_reads, uint8_t *pool, size_t pool_cap,
+                         size_t *pool_used, bmh_seed_task_t *tasks, int64_t task_cap)
+{
+	const int Lmax = cfg->len_max;
+	const int G = (p->w << 1) + Lmax + 8;
+	const int R = Lmax * 2 + 2 * G + 64;
+	uint8_t *ref = (uint8_t *)malloc((size_t)R), *rd = (uint8_t *)malloc((size_t)Lmax + 64);
+	int *rpos = (int *)malloc(sizeof(int) * ((size_t)Lmax + 64));
+	int64_t nt = 0, r;
+	size_t used = 0;
+	uint64_t s = cfg->seed;
+	for (r = 0; r < n_reads; ++r) {
+		sim_read_t o;
+		bmh_seed_task_t *t;
+		if (!sim_read(cfg, p, &s, G, R, ref, rd, rpos, &o)) continue;
+		if (used + (size_t)o.L + (size_t)(o.rmax1 - o.rmax0) + 16 > pool_cap || nt + 1 > task_cap) {
 			nt = -1;
 			break;
 		}
-		{
-			const uint64_t read_off = used, win_off = used + (uint64_t)L;
-			int lsc = best_len * p->a;
-			memcpy(pool + read_off, rd, (size_t)L);
-			memcpy(pool + win_off, ref + rmax0, (size_t)(rmax1 - rmax0));
-			used += (size_t)L + (size_t)(rmax1 - rmax0);
-			if (best_q > 0) { /* left extension */
-				bmh_ext_task_t *t = &tasks[nt];
-				const int tl = (int)(best_r - rmax0);
-				int sc = 0, bestsc = 0;
-				memset(t, 0, sizeof(*t));
-				t->q_off = read_off + (uint64_t)(best_q - 1), t->t_off = win_off + (uint64_t)(tl > 0 ? tl - 1 : 0);
-				t->qlen = (uint16_t)best_q, t->tlen = (uint16_t)tl, t->h0 = best_len * p->a;
-				t->w = (int16_t)p->w, t->end_bonus = (int16_t)p->pen_clip5, t->flags = BMH_F_QREV | BMH_F_TREV;
-				if (task_read) task_read[nt] = (uint32_t)r;
-				++nt;
-				for (i = best_q - 1; i >= 0; --i) { /* crude score of the true left alignment, for the right h0 */
-					sc += rpos[i] >= 0 ? p->a : -4;
-					if (sc > bestsc) bestsc = sc;
-				}
-				lsc += bestsc;
-			}
-			if (best_q + best_len < L) { /* right extension */
-				bmh_ext_task_t *t = &tasks[nt];
-				const int qe = best_q + best_len;
-				const int64_t re = best_r + best_len - rmax0;
-				memset(t, 0, sizeof(*t));
-				t->q_off = read_off + (uint64_t)qe, t->t_off = win_off + (uint64_t)re;
-				t->qlen = (uint16_t)(L - qe), t->tlen = (uint16_t)(rmax1 - rmax0 - re), t->h0 = lsc;
-				t->w = (int16_t)p->w, t->end_bonus = (int16_t)p->pen_clip3;
-				if (task_read) task_read[nt] = (uint32_t)r;
-				++nt;
-			}
-		}
+		t = &tasks[nt++];
+		memset(t, 0, sizeof(*t));
+		memcpy(pool + used, rd, (size_t)o.L);
+		memcpy(pool + used + o.L, ref + o.rmax0, (size_t)(o.rmax1 - o.rmax0));
+		t->q_off = used, t->t_off = used + (uint64_t)o.L, t->l_query = o.L, t->qbeg = o.best_q, t->len = o.best_len;
+		t->rbeg = (int32_t)(o.best_r - o.rmax0), t->wlen = (int32_t)(o.rmax1 - o.rmax0);
+		used += (size_t)o.L + (size_t)(o.rmax1 - o.rmax0);
 	}
 	free(ref), free(rd), free(rpos);
 	if (pool_used) *pool_used = used;

@@ -63,6 +63,27 @@ def generate(params, n_reads, workload="150bp", seed=7, ext_task_dtype=None):
     return pool, tasks[:nt].copy(), tread[:nt].copy()
 
 
+def generate_seeds(params, n_reads, workload="150bp", seed=7):
+    """Returns (pool uint8[], tasks SEED_TASK[]): one fused per-seed record per simulated (seeded) read."""
+    from . import SEED_TASK, PARAMS
+    L = _load()
+    L.bmh_taskgen_seed.restype = C.c_int64
+    cfg = Cfg(seed=seed, **WORKLOADS[workload])
+    p = np.ascontiguousarray(np.asarray(params, dtype=PARAMS).reshape(()))
+    bound = L.bmh_taskgen_pool_bound(C.byref(cfg), p.ctypes.data_as(C.c_void_p))
+    pool = np.empty(int(bound) * int(n_reads) + 64, dtype=np.uint8)
+    tasks = np.empty(int(n_reads) + 1, dtype=SEED_TASK)
+    used = C.c_size_t(0)
+    nt = L.bmh_taskgen_seed(C.byref(cfg), p.ctypes.data_as(C.c_void_p), C.c_int64(n_reads),
+                            pool.ctypes.data_as(C.c_void_p), C.c_size_t(pool.nbytes), C.byref(used),
+                            tasks.ctypes.data_as(C.c_void_p), C.c_int64(len(tasks)))
+    if nt < 0:
+        raise RuntimeError("taskgen capacity too small")
+    pool = pool[: used.value + 16]
+    pool[used.value:] = 0
+    return pool, tasks[:nt].copy()
+
+
 def generate_global(n_reads, workload="150bp", seed=11, wspread=32):
     """Returns (pool, tasks GLB_TASK[], cigar_words) -- one banded global alignment per simulated read."""
     from . import GLB_TASK

@@ -157,6 +157,51 @@ int bmh_extend_batch_sharded(bmh_ctx_t *const *ctxs, int n_ctx, const uint8_t *s
                              size_t pool_bytes, const bmh_ext_task_t *tasks, int64_t n,
                              bmh_ext_result_t *results);
 
+/* ---- L2.5: one record per SEED -- the accelerator record the fork sketched and never used
+ * (ext_param_t / ext_res_t, reference bwamem.c:553-577).  The device runs, for every seed, what
+ * mem_chain2aln does between bwamem.c:810 and :866: the left extension on the reversed flanks (up to MAX_BAND_TRY = 2
+ * band widths, retry rule :828), the clip-or-reach-the-end decision (:831-837), the right extension started from the
+ * LEFT SCORE (:842,854; retry rule :856), its decision (:859-865) -- and returns the finished region fields.  Inside
+ * the library that is four dependent rounds of ksw_extend2 batches (left, left at 2w, right, right at 2w), the
+ * retry lists and the right tasks built ON THE DEVICE from the previous round's results; nothing returns to the host
+ * in between, the whole call is asynchronous on the context's stream.
+ * ext_param_t gave the flanks as four pointers + lengths; here they are expressed by the seed's position inside the
+ * read and inside the chain's reference window [rmax0,rmax1) (bwamem.c:740-757), which is what the driver has. */
+typedef struct bmh_seed_task { /* 40 bytes */
+	uint64_t q_off;   /* pool offset of query base 0 (the whole read, base codes)                                  */
+	uint64_t t_off;   /* pool offset of rseq[0], i.e. of window base rmax0; with BMH_F_TPAC the doubled-coordinate
+	                     position rmax0 itself (the window is then read from the resident 2-bit reference)          */
+	int32_t l_query;  /* read length                                                                                */
+	int32_t qbeg, len;/* the seed on the query: mem_seed_t.qbeg / .len (bwamem.c:168-171); h0 = len * a            */
+	int32_t rbeg;     /* the seed inside the window: mem_seed_t.rbeg - rmax0  (left target length, bwamem.c:815)    */
+	int32_t wlen;     /* rmax1 - rmax0                                                                              */
+	uint16_t flags;   /* BMH_F_TPAC or 0                                                                            */
+	uint16_t rsv_;
+} bmh_seed_task_t;
+
+typedef struct bmh_seed_result { /* 32 bytes; ext_res_t (bwamem.c:568-577) in 32-bit fields */
+	int32_t qb, qe;        /* mem_alnreg_t.qb / .qe                                    (bwamem.c:832,835,860,863,866) */
+	int32_t rb, re;        /* mem_alnreg_t.rb / .re MINUS rmax0 (window-relative)                                     */
+	int32_t score, truesc; /* mem_alnreg_t.score / .truesc                                                            */
+	int32_t w;             /* max(aw[0], aw[1]), bwamem.c:875                                                         */
+	int32_t n_ext;         /* ksw_extend2 calls the reference would have made for this seed (0..4)                    */
+} bmh_seed_result_t;
+
+/* Range: qbeg, l_query-qbeg-len, rbeg, wlen-rbeg-len <= 65535, 2*w <= 32767, and the extension limits above. */
+int bmh_seedext_batch(bmh_ctx_t *ctx, const uint8_t *seqpool, size_t pool_bytes, const bmh_seed_task_t *tasks, int64_t n,
+                      bmh_seed_result_t *results); /* pool == NULL: the pool left by bmh_upload_pool() */
+int bmh_seedext_batch_device(bmh_ctx_t *ctx, const uint8_t *d_seqpool, const bmh_seed_task_t *d_tasks, int64_t n,
+                             bmh_seed_result_t *d_results);
+/* Two-step form of bmh_seedext_batch for callers that overlap host work with the device: _submit stages the tasks and
+ * enqueues everything (uploads, the four rounds, the download into the context's pinned buffer) and returns at once;
+ * _wait blocks until the results are there and copies them out.  One submission may be in flight per context. */
+int bmh_seedext_submit(bmh_ctx_t *ctx, const bmh_seed_task_t *tasks, int64_t n);
+int bmh_seedext_wait(bmh_ctx_t *ctx, bmh_seed_result_t *results);
+typedef struct bmh_seedext_stats { /* of the last completed bmh_seedext_batch / _wait (host-buffer forms only) */
+	int64_t seeds, left_tasks, left_retries, right_tasks, right_retries;
+} bmh_seedext_stats_t;
+int bmh_seedext_stats(const bmh_ctx_t *ctx, bmh_seedext_stats_t *st);
+
 /* ---- kernel timing: HIP events recorded on the context's stream around the
  * dominant kernel of the last *_device call.  ms < 0 if none. */
 int bmh_last_kernel_ms(bmh_ctx_t *ctx, float *ms);
@@ -164,6 +209,9 @@ int bmh_set_kernel_timing(bmh_ctx_t *ctx, int enable);
 /* Per-kernel duration of the last extension launch, one entry per query-length bin of the dispatcher:
  * qlen <= 32, <= 64, <= 128, <= 256, <= 512, longer (LDS kernel).  -1 when timing was off. */
 int bmh_last_extend_bin_ms(bmh_ctx_t *ctx, float ms[6]);
+/* Per-kernel duration of the last global-alignment launch: the 64-slot lane kernel (w <= 31), the 128-slot one (w <= 63),
+ * the one-wave-per-task kernel (everything else).  -1 when timing was off. */
+int bmh_last_global_bin_ms(bmh_ctx_t *ctx, float ms[3]);
 
 /* ---- L3: data carriers of the extension driver, layout-compatible with the
  * reference so that its structs can be passed straight through. */
@@ -249,6 +297,7 @@ int bmh_reg2cigar_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, const
 typedef struct bmh_driver_stats {
 	int64_t rounds, ext_tasks, seeds_extended, seeds_skipped;
 	int64_t pool_bytes; /* bytes of sequence shipped to the device for the call */
+	int64_t seeds_speculated; /* seeds the device extended ahead of the replay whose result was not needed */
 } bmh_driver_stats_t;
 int bmh_driver_stats(const bmh_ctx_t *ctx, bmh_driver_stats_t *st);
 

@@ -88,19 +88,135 @@ static int seed_near_region(const bmh_params_t *p, const bmh_seed_t *s, const bm
 	return 0;
 }
 
+/* What mem_chain2aln does for ONE seed once it has decided to extend it (bwamem.c:808-866): left extension on the
+ * reversed flanks with up to MAX_BAND_TRY band widths, the clip-or-reach-the-end decision, right extension started from
+ * the left score, its decision.  `rseq` is the chain's window [rmax0,rmax1), `rbeg` the seed's start inside it.
+ * Result coordinates rb/re are window-relative.  This is the record the fork sketched as ext_param_t/ext_res_t
+ * (bwamem.c:553-577); orc_chain2aln below is built on it, so the reference fixtures of mem_chain2aln pin it. */
+void orc_seedext_one(const bmh_params_t *p, const uint8_t *query, int l_query, const uint8_t *rseq, int wlen, int qbeg, int len,
+                     int rbeg, bmh_seed_result_t *r, int64_t *cells, int64_t *calls)
+{
+	orc_scoring_t sc;
+	orc_extend_stats_t st;
+	int i, aw0 = p->w, aw1 = p->w, score = -1, truesc = -1, n_ext = 0;
+	sc.o_del = p->o_del, sc.e_del = p->e_del, sc.o_ins = p->o_ins, sc.e_ins = p->e_ins;
+	sc.zdrop = p->zdrop, sc.m = 5, sc.mat = p->mat;
+	if (qbeg) { /* left extension on reversed flanks.  bwamem.c:810-838 */
+		int tl = rbeg, ql = qbeg;
+		uint8_t *qs = (uint8_t *)malloc((size_t)ql + 1), *rs = (uint8_t *)malloc((size_t)tl + 1);
+		orc_extend_out_t o;
+		for (i = 0; i < ql; ++i) qs[i] = query[ql - 1 - i];
+		for (i = 0; i < tl; ++i) rs[i] = rseq[tl - 1 - i];
+		memset(&o, 0, sizeof(o));
+		for (i = 0; i < 2; ++i) { /* MAX_BAND_TRY, bwamem.c:493 */
+			int prev = score;
+			aw0 = p->w << i;
+			orc_extend(&sc, ql, qs, tl, rs, aw0, p->pen_clip5, len * p->a, &o, &st);
+			++n_ext;
+			if (cells) *cells += st.cells;
+			score = o.score;
+			if (score == prev || o.max_off < (aw0 >> 1) + (aw0 >> 2)) break;
+		}
+		if (o.gscore <= 0 || o.gscore <= score - p->pen_clip5) { /* clip.  bwamem.c:831-833 */
+			r->qb = qbeg - o.qle, r->rb = rbeg - o.tle;
+			truesc = score;
+		} else { /* reach the read end.  bwamem.c:834-837 */
+			r->qb = 0, r->rb = rbeg - o.gtle;
+			truesc = o.gscore;
+		}
+		free(qs);
+		free(rs);
+	} else score = truesc = len * p->a, r->qb = 0, r->rb = rbeg; /* bwamem.c:839 */
+
+	if (qbeg + len != l_query) { /* right extension.  bwamem.c:841-865 */
+		int sc0 = score, qe = qbeg + len, re = rbeg + len;
+		orc_extend_out_t o;
+		memset(&o, 0, sizeof(o));
+		for (i = 0; i < 2; ++i) {
+			int prev = score;
+			aw1 = p->w << i;
+			orc_extend(&sc, l_query - qe, query + qe, wlen - re, rseq + re, aw1, p->pen_clip3, sc0, &o, &st);
+			++n_ext;
+			if (cells) *cells += st.cells;
+			score = o.score;
+			if (score == prev || o.max_off < (aw1 >> 1) + (aw1 >> 2)) break;
+		}
+		if (o.gscore <= 0 || o.gscore <= score - p->pen_clip3) {
+			r->qe = qe + o.qle, r->re = re + o.tle;
+			truesc += score - sc0;
+		} else {
+			r->qe = l_query, r->re = re + o.gtle;
+			truesc += o.gscore - sc0;
+		}
+	} else r->qe = l_query, r->re = rbeg + len; /* bwamem.c:866 */
+	r->score = score, r->truesc = truesc, r->w = imax(aw0, aw1), r->n_ext = n_ext;
+	if (calls) *calls += n_ext;
+}
+
+/* ---- batch form over bmh_seed_task_t records (tests, bench CPU baseline): plain loop, optionally on pthreads */
+#include <pthread.h>
+typedef struct {
+	const bmh_params_t *p;
+	const uint8_t *pool, *pac;
+	int64_t l_pac;
+	const bmh_seed_task_t *t;
+	bmh_seed_result_t *r;
+	int64_t lo, hi, cells, calls;
+} seed_job_t;
+
+static void *seed_worker(void *arg)
+{
+	seed_job_t *j = (seed_job_t *)arg;
+	int64_t k;
+	for (k = j->lo; k < j->hi; ++k) {
+		const bmh_seed_task_t *t = &j->t[k];
+		const uint8_t *rseq = j->pool + t->t_off;
+		uint8_t *own = 0;
+		if (t->flags & BMH_F_TPAC) { /* window read from the 2-bit reference: bns_get_seq, bntseq.c:355-376 */
+			int64_t len;
+			own = orc_get_seq(j->l_pac, j->pac, (int64_t)t->t_off, (int64_t)t->t_off + t->wlen, &len);
+			rseq = own;
+		}
+		orc_seedext_one(j->p, j->pool + t->q_off, t->l_query, rseq, t->wlen, t->qbeg, t->len, t->rbeg, &j->r[k], &j->cells, &j->calls);
+		free(own);
+	}
+	return 0;
+}
+
+int orc_seedext_batch(const bmh_params_t *p, const uint8_t *pool, const uint8_t *pac, int64_t l_pac, const bmh_seed_task_t *tasks,
+                      int64_t n, bmh_seed_result_t *results, int64_t *cells_out, int64_t *calls_out, int nthreads)
+{
+	pthread_t th[256];
+	seed_job_t job[256];
+	int k;
+	if (nthreads < 1) nthreads = 1;
+	if (nthreads > 256) nthreads = 256;
+	for (k = 0; k < nthreads; ++k) {
+		job[k].p = p, job[k].pool = pool, job[k].pac = pac, job[k].l_pac = l_pac, job[k].t = tasks, job[k].r = results;
+		job[k].lo = n * k / nthreads, job[k].hi = n * (k + 1) / nthreads, job[k].cells = job[k].calls = 0;
+		if (nthreads > 1) pthread_create(&th[k], 0, seed_worker, &job[k]);
+		else seed_worker(&job[k]);
+	}
+	if (cells_out) *cells_out = 0;
+	if (calls_out) *calls_out = 0;
+	for (k = 0; k < nthreads; ++k) {
+		if (nthreads > 1) pthread_join(th[k], 0);
+		if (cells_out) *cells_out += job[k].cells;
+		if (calls_out) *calls_out += job[k].calls;
+	}
+	return 0;
+}
+
 void orc_chain2aln(const bmh_params_t *p, int64_t l_pac, const uint8_t *pac, int l_query,
                    const uint8_t *query, const bmh_chain_t *c, bmh_alnreg_v *av,
                    orc_driver_trace_t *trace)
 {
-	orc_scoring_t sc;
 	int i, k;
 	int64_t rmax0, rmax1, rlen;
 	uint8_t *rseq;
 	uint64_t *srt;
 
 	if (c->n == 0) return; /* bwamem.c:738 */
-	sc.o_del = p->o_del, sc.e_del = p->e_del, sc.o_ins = p->o_ins, sc.e_ins = p->e_ins;
-	sc.zdrop = p->zdrop, sc.m = 5, sc.mat = p->mat;
 
 	/* reference window covering every seed's maximal extension.  bwamem.c:740-755 */
 	rmax0 = l_pac << 1, rmax1 = 0;
@@ -149,57 +265,15 @@ void orc_chain2aln(const bmh_params_t *p, int64_t l_pac, const uint8_t *pac, int
 
 		a = regs_push(av); /* bwamem.c:804-807 */
 		memset(a, 0, sizeof(*a));
-		a->w = aw0 = aw1 = p->w;
-		a->score = a->truesc = -1;
-
-		if (s->qbeg) { /* left extension on reversed flanks.  bwamem.c:810-838 */
-			int tl = (int)(s->rbeg - rmax0), ql = s->qbeg;
-			uint8_t *qs = (uint8_t *)malloc((size_t)ql + 1), *rs = (uint8_t *)malloc((size_t)tl + 1);
-			orc_extend_out_t o;
-			for (i = 0; i < ql; ++i) qs[i] = query[ql - 1 - i];
-			for (i = 0; i < tl; ++i) rs[i] = rseq[tl - 1 - i];
-			memset(&o, 0, sizeof(o));
-			for (i = 0; i < 2; ++i) { /* MAX_BAND_TRY, bwamem.c:493 */
-				int prev = a->score;
-				aw0 = p->w << i;
-				orc_extend(&sc, ql, qs, tl, rs, aw0, p->pen_clip5, s->len * p->a, &o, 0);
-				if (trace) trace->ext_calls++;
-				a->score = o.score;
-				if (a->score == prev || o.max_off < (aw0 >> 1) + (aw0 >> 2)) break;
-			}
-			if (o.gscore <= 0 || o.gscore <= a->score - p->pen_clip5) { /* clip.  bwamem.c:831-833 */
-				a->qb = s->qbeg - o.qle, a->rb = s->rbeg - o.tle;
-				a->truesc = a->score;
-			} else { /* reach the read end.  bwamem.c:834-837 */
-				a->qb = 0, a->rb = s->rbeg - o.gtle;
-				a->truesc = o.gscore;
-			}
-			free(qs);
-			free(rs);
-		} else a->score = a->truesc = s->len * p->a, a->qb = 0, a->rb = s->rbeg; /* bwamem.c:839 */
-
-		if (s->qbeg + s->len != l_query) { /* right extension.  bwamem.c:841-865 */
-			int sc0 = a->score, qe = s->qbeg + s->len;
-			int re = (int)(s->rbeg + s->len - rmax0);
-			orc_extend_out_t o;
-			memset(&o, 0, sizeof(o));
-			for (i = 0; i < 2; ++i) {
-				int prev = a->score;
-				aw1 = p->w << i;
-				orc_extend(&sc, l_query - qe, query + qe, (int)(rmax1 - rmax0 - re), rseq + re, aw1,
-				           p->pen_clip3, sc0, &o, 0);
-				if (trace) trace->ext_calls++;
-				a->score = o.score;
-				if (a->score == prev || o.max_off < (aw1 >> 1) + (aw1 >> 2)) break;
-			}
-			if (o.gscore <= 0 || o.gscore <= a->score - p->pen_clip3) {
-				a->qe = qe + o.qle, a->re = rmax0 + re + o.tle;
-				a->truesc += a->score - sc0;
-			} else {
-				a->qe = l_query, a->re = rmax0 + re + o.gtle;
-				a->truesc += o.gscore - sc0;
-			}
-		} else a->qe = l_query, a->re = s->rbeg + s->len; /* bwamem.c:866 */
+		{ /* both extensions of the seed and their decisions: bwamem.c:808-866, see orc_seedext_one */
+			bmh_seed_result_t sr;
+			int64_t calls = 0;
+			orc_seedext_one(p, query, l_query, rseq, (int)(rmax1 - rmax0), s->qbeg, s->len, (int)(s->rbeg - rmax0), &sr, 0, &calls);
+			if (trace) trace->ext_calls += calls;
+			a->qb = sr.qb, a->qe = sr.qe, a->rb = rmax0 + sr.rb, a->re = rmax0 + sr.re;
+			a->score = sr.score, a->truesc = sr.truesc;
+			aw0 = sr.w, aw1 = sr.w; /* a->w = max(aw0, aw1) below */
+		}
 
 		/* seed coverage.  bwamem.c:870-874 */
 		for (i = 0, a->seedcov = 0; i < c->n; ++i) {

@@ -24,6 +24,12 @@ void orc_chain2aln(const bmh_params_t *p, int64_t l_pac, const uint8_t *pac, int
                    const uint8_t *query, const bmh_chain_t *c, bmh_alnreg_v *av,
                    orc_driver_trace_t *trace /* nullable */);
 
+/* one seed: bwamem.c:808-866 (the fused record of SURVEY.md §8 row a5); window-relative rb/re */
+void orc_seedext_one(const bmh_params_t *p, const uint8_t *query, int l_query, const uint8_t *rseq, int wlen, int qbeg, int len,
+                     int rbeg, bmh_seed_result_t *r, int64_t *cells /* nullable, += */, int64_t *calls /* nullable, += */);
+int orc_seedext_batch(const bmh_params_t *p, const uint8_t *pool, const uint8_t *pac, int64_t l_pac, const bmh_seed_task_t *tasks,
+                      int64_t n, bmh_seed_result_t *results, int64_t *cells_out, int64_t *calls_out, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

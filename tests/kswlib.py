@@ -28,6 +28,11 @@ EXT_RES = np.dtype([("score", "<i4"), ("qle", "<i4"), ("tle", "<i4"), ("gtle", "
 GLB_TASK = np.dtype([("q_off", "<u8"), ("t_off", "<u8"), ("qlen", "<u2"), ("tlen", "<u2"),
                      ("w", "<i4"), ("cigar_off", "<u4"), ("cigar_cap", "<u4")])
 GLB_RES = np.dtype([("score", "<i4"), ("n_cigar", "<i4")])
+SEED_TASK = np.dtype([("q_off", "<u8"), ("t_off", "<u8"), ("l_query", "<i4"), ("qbeg", "<i4"), ("len", "<i4"),
+                      ("rbeg", "<i4"), ("wlen", "<i4"), ("flags", "<u2"), ("rsv", "<u2")])
+SEED_RES = np.dtype([("qb", "<i4"), ("qe", "<i4"), ("rb", "<i4"), ("re", "<i4"), ("score", "<i4"), ("truesc", "<i4"),
+                     ("w", "<i4"), ("n_ext", "<i4")])
+assert SEED_TASK.itemsize == 40 and SEED_RES.itemsize == 32
 PARAMS = np.dtype([("o_del", "<i4"), ("e_del", "<i4"), ("o_ins", "<i4"), ("e_ins", "<i4"),
                    ("zdrop", "<i4"), ("a", "<i4"), ("w", "<i4"), ("pen_clip5", "<i4"),
                    ("pen_clip3", "<i4"), ("mat", "i1", (25,)), ("pad", "i1", (3,))])
@@ -189,6 +194,23 @@ def orc_extend_batch(p, pool, tasks, nthreads=1, pac=None, l_pac=0):
                              tasks.ctypes.data_as(C.c_void_p), C.c_int(len(tasks)), out.ctypes.data_as(C.c_void_p),
                              C.byref(cells), C.c_int(nthreads))
     return out, cells.value
+
+
+def orc_seedext_batch(p, pool, tasks, nthreads=1, pac=None, l_pac=0):
+    """OUR restatement of bwamem.c:808-866 per seed record; returns (results SEED_RES[], cells, ksw_extend2 calls)."""
+    lib = load_oracle()
+    pp = np.ascontiguousarray(np.asarray(p, dtype=PARAMS).reshape(()))
+    tasks = np.ascontiguousarray(tasks, dtype=SEED_TASK)
+    pool = np.ascontiguousarray(pool, dtype=np.uint8)
+    if pac is not None:
+        pac = np.ascontiguousarray(pac, dtype=np.uint8)
+    out = np.zeros(len(tasks), dtype=SEED_RES)
+    cells, calls = C.c_int64(0), C.c_int64(0)
+    lib.orc_seedext_batch(pp.ctypes.data_as(C.c_void_p), pool.ctypes.data_as(C.c_void_p),
+                          pac.ctypes.data_as(C.c_void_p) if pac is not None else None, C.c_int64(l_pac),
+                          tasks.ctypes.data_as(C.c_void_p), C.c_int64(len(tasks)), out.ctypes.data_as(C.c_void_p),
+                          C.byref(cells), C.byref(calls), C.c_int(nthreads))
+    return out, cells.value, calls.value
 
 
 def sw_task_seqs(pool, t, pac=None, l_pac=0):
