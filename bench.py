@@ -1,23 +1,34 @@
 #!/usr/bin/env python3
-"""bench.py -- throughput of the seed-extension hot path (ksw_extend2 batches) on MI355X.
+"""bench.py -- throughput of BWA-MEM's dynamic-programming hot path on MI355X, on BASELINE.json's metric configuration.
 
-A "step" is one pass of the hot path over one batch of synthetic input: the extension
-tasks mem_chain2aln would build for `--reads` simulated reads (per GPU), already resident
-in HBM when the timed region starts, run by ONE bmh_extend_batch_device() call through the
-C-ABI of libbwamem_hip.so.  Weak scaling: every rank owns its own batch, no collective on
-the data path; torch.distributed is used only for the barrier and the
-max-over-ranks timing.
+Default workload `pe10m` = BASELINE.json configs[2]: 10 M x 150 bp read pairs (20 M reads) per GPU per step.  The GRCh38
+index cannot be built here (no genome data, `bwa index` of 3.1 Gb takes hours), so -- as SURVEY.md §8d / BASELINE.md §3
+prescribe -- the kernels are driven by a task generator that reproduces the measured task distribution of the
+reference pipeline; per-read DP work does not depend on the genome.  A STEP is one pass of the whole DP path over the
+20 M reads, streamed through HBM in chunks, inputs resident when the timed region starts:
 
-Prints ONE JSON line (rank 0).  metric = BASELINE.json's "aligned reads/sec".
+  1. seed extension  one fused record per seeded read (bmh_seedext_batch_device, reference bwamem.c:808-866 over
+                     ksw_extend2): left extension -> band retry -> clip decision -> RIGHT extension started from the
+                     left score the device just computed -> retry -> finished region;   ~1.47 ksw_extend2 per read
+  2. global          ksw_global2 + traceback (bmh_global_batch_device, bwa.c:132): 0.85 tasks per read at the measured
+                     band distribution (mean w 19.6)
+  3. mate rescue     ksw_align2 (bmh_sw_batch_device, bwamem_pair.c:148): --rescue-rate x pairs tasks (measured 2-11 %
+                     of the pairs; 4.5 % on the synthetic PE set of profiles/r01_pipeline_pe_*)
 
-Beside the contract fields the line carries, at N=1, three secondary measurements of the other kernels on the path and
-around it (each with its own parity check and CPU figure): `global_alignment` (ksw_global2 + traceback),
-`mate_rescue_sw` (ksw_align2) and `seeding_fmindex` (bwt_smem1 / bwt_sa; needs oracle/_ref to build an index).
+`value` = reads of the step / time of the step (a pair counts as two reads), max over ranks.  What is NOT in a step: FM-index
+seeding, chaining, SAM text (host stages either side of the path); their cost shows in `cpu_baseline_pipeline`, which
+times the reference's own `bwa mem` (all host cores) and the same binary with this library preloaded, SAM-identical.
+
+`--workload se1m` runs round 1's line (tools/bench_se1m.py: one flat ksw_extend2 batch over configs[1]-shaped tasks).
+Prints ONE JSON line (rank 0).
 """
 import argparse
 import json
 import os
+import re
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -27,37 +38,165 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+_T0 = time.time()
 
 
+def note(msg):
+    """progress on stderr (the JSON line on stdout stays alone)"""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.time() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# whole-pipeline baseline: the reference's own `bwa mem` vs the same binary with the library preloaded
+def _fastq_fixed(path, reads, prefix):
+    """FASTQ with fixed-width names: every record has the same length, so the file is one numpy reshape."""
+    n, L = reads.shape
+    name = np.frombuffer(("".join("@%s%08d\n" % (prefix, i) for i in range(n))).encode(), dtype=np.uint8).reshape(n, -1)
+    seq = np.frombuffer(b"ACGTN", dtype=np.uint8)[reads]
+    nl = np.full((n, 1), 10, np.uint8)
+    plus = np.tile(np.frombuffer(b"+\n", dtype=np.uint8), (n, 1))
+    qual = np.full((n, L), ord("I"), np.uint8)
+    np.concatenate([name, seq, nl, plus, qual, nl], axis=1).tofile(path)
+
+
+def pipeline_baseline(n_reads, genome_bp, threads, batch=8192, noisy=0.3, dut=True):
+    """REF and DUT reads/s from the reference's own `[M::mem_process_seqs] Processed N reads in ... real sec` lines
+    (bwamem.c:1320-1321; index loading excluded), paired-end, SAM compared (minus @PG)."""
+    import kswgen
+    import reflib
+    from __graft_entry__ import load_package
+    if not reflib.have_ref_bwa():
+        return {"skipped": "oracle/_ref/bwa absent (it is built where /root/reference exists and travels with the tree)"}
+    rng = np.random.default_rng(20261101)
+    tmp = tempfile.mkdtemp(prefix="bmh_pipe_")
+    ref = kswgen.rand_seq(rng, genome_bp)
+    fa = os.path.join(tmp, "ref.fa")
+    reflib.write_fasta(fa, "synth", ref)
+    t0 = time.time()
+    reflib.build_index(fa)
+    t_index = time.time() - t0
+    n_pairs, L = n_reads // 2, 150
+    ins = rng.integers(250, 450, size=n_pairs)
+    pos = rng.integers(0, len(ref) - 520, size=n_pairs)
+    idx = np.arange(L)[None, :]
+    a = ref[pos[:, None] + idx]
+    b = ref[(pos + ins - L)[:, None] + idx]
+    rate_b = np.where(rng.random(n_pairs) < noisy, 0.12, 0.02)[:, None]
+    for arr, rate in ((a, 0.02), (b, rate_b)):
+        sub = rng.random(arr.shape) < rate
+        arr[sub] = (arr[sub] + rng.integers(1, 4, size=int(sub.sum()))) & 3
+    b = 3 - b[:, ::-1]
+    fq = [os.path.join(tmp, "r1.fq"), os.path.join(tmp, "r2.fq")]
+    _fastq_fixed(fq[0], a, "p")
+    _fastq_fixed(fq[1], b, "p")
+
+    def run(preload, out, t):
+        note(f"pipeline baseline: bwa mem -t {t} {'with the library preloaded' if preload else '(reference)'}")
+        env = dict(os.environ)
+        if preload:
+            env["LD_PRELOAD"] = load_package().DROPIN_PATH
+            env["BMH_KSW_DROPIN"] = "1"  # every remaining per-call ksw_* goes to the GPU too: all DP on the device
+            env["BMH_VERBOSE"] = "1"
+        t0 = time.time()
+        with open(out, "w") as f:
+            try:
+                p = subprocess.run([reflib.REF_BWA, "mem", "-t", str(t), "-b", str(batch), fa] + fq, stdout=f, stderr=subprocess.PIPE,
+                                   env=env, timeout=300)
+            except subprocess.TimeoutExpired as e:
+                return {"error": "timed out after 300 s: " + (e.stderr or b"").decode(errors="replace")[-400:]}
+        err = p.stderr.decode(errors="replace")
+        if p.returncode != 0:
+            return {"error": err[-400:]}
+        reads = real = 0
+        for m in re.finditer(r"Processed (\d+) reads in ([\d.]+) CPU sec, ([\d.]+) real sec", err):
+            reads += int(m.group(1))
+            real += float(m.group(3))
+        miss = re.findall(r"served (\d+) calls from the batch, (\d+) went to the host", err)
+        return {"reads": reads, "real_s": real, "reads_per_s": reads / real if real else None, "wall_s": time.time() - t0,
+                "cigar_table": {"served": int(miss[-1][0]), "to_host": int(miss[-1][1])} if miss else None}
+
+    if dut:
+        run(True, os.path.join(tmp, "warm.sam"), min(threads, 16))  # page the HIP runtime + code objects in (seconds on a fresh box)
+    r = run(False, os.path.join(tmp, "ref.sam"), threads)
+    d = run(True, os.path.join(tmp, "dut.sam"), threads) if dut else {"error": "not run"}
+    same = None
+    if "error" not in r and "error" not in d:
+        same = [l for l in open(os.path.join(tmp, "ref.sam")) if not l.startswith("@PG")] == \
+               [l for l in open(os.path.join(tmp, "dut.sam")) if not l.startswith("@PG")]
+    out = {"value": r.get("reads_per_s"), "unit": "reads/s", "cores": threads, "kind": "reference",
+           "sample": f"{n_reads} x 150 bp paired-end reads vs a {genome_bp} bp synthetic genome, oracle/_ref/bwa mem -t {threads} -b {batch}; "
+                     f"reads/s from the reference's own per-chunk 'Processed ... real sec' lines",
+           "dut_value": d.get("reads_per_s"), "dut": "same binary, LD_PRELOAD=libbwamem_hip_dropin.so, BMH_KSW_DROPIN=1, same -t",
+           "dut_over_ref": (d["reads_per_s"] / r["reads_per_s"]) if r.get("reads_per_s") and d.get("reads_per_s") else None,
+           "sam_identical": same, "ref": r, "dut_detail": d, "index_s": t_index}
+    for f in os.listdir(tmp):
+        os.unlink(os.path.join(tmp, f))
+    os.rmdir(tmp)
+    return out
+
+
+def host_cores():
+    """(threads usable by this process, what limits them)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    note = f"{n} hardware threads in the affinity mask"
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            note += f", cgroup cpu.max {q}/{per} = {int(q) / int(per):.1f} CPUs"
+    except Exception:
+        pass
+    return n, note
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--reads", type=int, default=1_000_000, help="simulated reads per GPU per step")
-    ap.add_argument("--workload", default="150bp", choices=["150bp", "250bp", "mixed100-300"])
-    ap.add_argument("--sw-tasks", type=int, default=400_000,
-                    help="mate-rescue Smith-Waterman tasks for the secondary measurement (0 = skip)")
-    ap.add_argument("--seed-reads", type=int, default=200_000,
-                    help="reads for the secondary FM-index (seeding) measurement; needs oracle/_ref to build an index (0 = skip)")
-    ap.add_argument("--target-source", default="pool", choices=["pool", "pac"],
-                    help="pac: targets decoded on the fly from a 2-bit reference resident in HBM (BMH_F_TPAC)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (rank 0, N=1 only)")
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="pe10m", choices=["pe10m", "se1m"])
+    ap.add_argument("--shape", default="150bp", choices=["150bp", "250bp", "mixed100-300"], help="read model of the task generator")
+    ap.add_argument("--pairs", type=int, default=10_000_000, help="read pairs per GPU per step (pe10m)")
+    ap.add_argument("--chunk-reads", type=int, default=1_000_000, help="reads per streamed chunk")
+    ap.add_argument("--global-per-read", type=float, default=0.85, help="ksw_global2 tasks per read (measured, SURVEY.md §8a2)")
+    ap.add_argument("--rescue-rate", type=float, default=0.06, help="ksw_align2 mate-rescue tasks per pair (measured 0.02-0.11)")
+    ap.add_argument("--streams", type=int, default=1, help="1: the three stages of a chunk back to back on one stream; 3: one context and stream per stage")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the oracle-port CPU baseline (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--global-tasks", type=int, default=250_000,
-                    help="size of the secondary ksw_global2 measurement (0 = skip); rank 0 at N=1 only")
-    args = ap.parse_args()
+    ap.add_argument("--no-pipeline-baseline", action="store_true")
+    ap.add_argument("--pipeline-reads", type=int, default=400_000)
+    ap.add_argument("--pipeline-genome", type=int, default=4_600_000)
+    args, rest = ap.parse_known_args()
+    if args.workload == "se1m":
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_se1m
+        return bench_se1m.main(["--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--shape", args.shape] +
+                               (["--no-cpu-baseline"] if args.no_cpu_baseline else []) + rest)
+    if rest:
+        ap.error("unknown arguments: " + " ".join(rest))
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    ncores, cores_note = host_cores()
+
+    # ---- whole-pipeline CPU baseline FIRST: it starts child processes, and this process has not touched the GPU yet
+    pipe = None
+    if world == 1 and rank == 0 and not args.no_pipeline_baseline and args.pipeline_reads > 0:
+        try:
+            pipe = pipeline_baseline(args.pipeline_reads, args.pipeline_genome, ncores)
+            pipe["cores_note"] = cores_note
+        except Exception as e:  # a baseline must never take the measurement down with it
+            pipe = {"skipped": f"{type(e).__name__}: {e}"}
 
     import torch
     import torch.distributed as dist
     from __graft_entry__ import load_package
     import kswlib  # record layouts + the oracle binding (checker / cpu_baseline only)
+    import importlib
+    from concurrent.futures import ThreadPoolExecutor
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    # under torch.distributed.run (RANK set) the process group is always created -- also for one rank -- so the
-    # RCCL path is the same code at N=1,2,4,8; a bare `python bench.py` stays single-process
     use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -66,344 +205,265 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-
     pkg = load_package()
-    import importlib
     tg = importlib.import_module("bwa_mem_quickassist_amd.taskgen")
     sh = importlib.import_module("bwa_mem_quickassist_amd.shard")
-
-    # ---- workload: this rank's shard (distinct seed per rank, same size: weak scaling)
     params = kswlib.make_params()  # bwa mem defaults, reference bwamem.c:45-75
+
+    # ---- this rank's shard (weak scaling: same size, distinct seeds), generated chunk by chunk on host threads
+    n_reads_step = 2 * args.pairs
+    n_chunks = max(1, (n_reads_step + args.chunk_reads - 1) // args.chunk_reads)
+    sizes = [n_reads_step * (k + 1) // n_chunks - n_reads_step * k // n_chunks for k in range(n_chunks)]
     t0 = time.time()
-    pool, tasks, tread = tg.generate(params, args.reads, args.workload, seed=sh.shard_seed(7, rank))
-    n_tasks = len(tasks)
-    n_reads_used = int(len(np.unique(tread)))
+
+    def gen(k):
+        s0 = sh.shard_seed(7, rank) * 131 + 17 * k
+        nr = sizes[k]
+        pool, seeds = tg.generate_seeds(params, nr, args.shape, seed=s0)
+        gpool, gtasks, gwords = tg.generate_global(max(1, int(round(nr * args.global_per_read))), args.shape, seed=s0 + 5)
+        spool, stasks = tg.generate_sw(params, max(1, int(round(nr / 2 * args.rescue_rate))), args.shape, seed=s0 + 9)
+        return pool, seeds, gpool, gtasks, gwords, spool, stasks
+
+    workers = max(1, min(16, ncores, n_chunks))
+    note(f"generating {n_reads_step} reads' worth of tasks in {n_chunks} chunks on {workers} threads")
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        host = list(ex.map(gen, range(n_chunks)))
     gen_s = time.time() - t0
-    pac, l_pac = None, 0
-    if args.target_source == "pac":
-        # the byte pool doubles as the forward strand of a synthetic genome: same tasks, same answers, but the
-        # kernels fetch target bases from the packed copy (position on the doubled coordinate = pool offset)
-        l_pac = len(pool)
-        q = np.concatenate([pool & 3, np.zeros((-l_pac) % 4 + 4, np.uint8)])
-        q = q[: len(q) // 4 * 4].reshape(-1, 4)
-        pac = (q[:, 0] << 6 | q[:, 1] << 4 | q[:, 2] << 2 | q[:, 3]).astype(np.uint8)
-        tasks["flags"] |= pkg.BMH_F_TPAC
-    alg_bytes = int(tasks["qlen"].astype(np.int64).sum() + tasks["tlen"].astype(np.int64).sum() + 56 * n_tasks)
 
-    d_pool = torch.from_numpy(pool).to(dev)
-    d_tasks = torch.from_numpy(tasks.view(np.uint8)).to(dev)
-    d_res = torch.zeros(n_tasks * pkg.EXT_RES.itemsize, dtype=torch.uint8, device=dev)
+    note(f"generated in {gen_s:.1f} s; uploading")
+    t0 = time.time()
+    chunks = []
+    up = lambda a: torch.from_numpy(a.view(np.uint8).reshape(-1)).to(dev)
+    for pool, seeds, gpool, gtasks, gwords, spool, stasks in host:
+        chunks.append({"pool": up(pool), "seeds": up(seeds), "n": len(seeds), "gpool": up(gpool), "gtasks": up(gtasks), "ng": len(gtasks),
+                       "gwords": gwords, "spool": up(spool), "stasks": up(stasks), "ns": len(stasks),
+                       "sres": torch.zeros(len(seeds) * pkg.SEED_RES.itemsize, dtype=torch.uint8, device=dev),
+                       "gres": torch.zeros(len(gtasks) * pkg.GLB_RES.itemsize, dtype=torch.uint8, device=dev),
+                       "swres": torch.zeros(len(stasks) * pkg.SW_RES.itemsize, dtype=torch.uint8, device=dev)})
+    d_cig = torch.zeros(max(c["gwords"] for c in chunks) + 8, dtype=torch.int32, device=dev)  # one chunk's CIGARs at a time
+    upload_s = time.time() - t0
+    n_seeded = sum(c["n"] for c in chunks)
+    n_glb, n_sw = sum(c["ng"] for c in chunks), sum(c["ns"] for c in chunks)
+    qmax = int(max(max(int(h[1]["qbeg"].max()), int((h[1]["l_query"] - h[1]["qbeg"] - h[1]["len"]).max())) for h in host))
+    gqmax = int(max(int(h[3]["qlen"].max()) for h in host))
 
-    ctx = pkg.Context(local_rank, params)
-    ctx.set_qcap(int(tasks["qlen"].max()))
-    if pac is not None:
-        ctx.set_pac(pac, l_pac)
-    # a dedicated (non-null) torch stream: the kernel is launched on it through the C-ABI and the
-    # HIP events that time it are recorded on the same stream
     stream = torch.cuda.Stream(dev)
     assert stream.cuda_stream != 0
-    ctx.set_stream(stream.cuda_stream)
+    ctxs = [pkg.Context(local_rank, params) for _ in range(3 if args.streams == 3 else 1)]
+    streams = [stream] + [torch.cuda.Stream(dev) for _ in ctxs[1:]]
+    for c, s in zip(ctxs, streams):
+        c.set_qcap(max(qmax, gqmax))
+        c.set_stream(s.cuda_stream)
+    cx_ext, cx_glb, cx_sw = ctxs[0], ctxs[1 % len(ctxs)], ctxs[2 % len(ctxs)]
     torch.cuda.synchronize(dev)
 
+    def run_chunk(c, cig):
+        cx_ext.seedext_batch_device(c["pool"].data_ptr(), c["seeds"].data_ptr(), c["n"], c["sres"].data_ptr())
+        cx_glb.global_batch_device(c["gpool"].data_ptr(), c["gtasks"].data_ptr(), c["ng"], c["gres"].data_ptr(), cig.data_ptr())
+        cx_sw.sw_batch_device(c["spool"].data_ptr(), c["stasks"].data_ptr(), c["ns"], c["swres"].data_ptr())
+
     def step():
-        ctx.extend_batch_device(d_pool.data_ptr(), d_tasks.data_ptr(), n_tasks, d_res.data_ptr())
+        for c in chunks:
+            run_chunk(c, d_cig)
+
+    def sync_all():
+        for s in streams:
+            s.synchronize()
 
     def barrier():
         torch.cuda.synchronize(dev)
         if use_dist:
             dist.barrier()
 
-    ctx.set_kernel_timing(True)  # HIP events around each extension kernel, on the launch stream
+    note(f"uploaded in {upload_s:.1f} s; warm-up")
     for _ in range(args.warmup):
         step()
     barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    note("timing")
     t_start = time.perf_counter()
-    ev0.record(stream)
     for _ in range(args.steps):
         step()
-    ev1.record(stream)
+    sync_all()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t_start
-    step_kernels_ms = ev0.elapsed_time(ev1) / args.steps  # all kernels of a step, HIP events on the launch stream
-    bin_ms = ctx.last_extend_bin_ms()                      # per kernel, last timed step
-    ctx.sync()  # surfaces any BMH_E_RANGE flagged by the kernel
+    for c in ctxs:
+        c.sync()  # surfaces any BMH_E_RANGE / BMH_E_CIGAR_CAP flagged by a kernel
     if use_dist:
         dist.barrier()
-    elapsed, reads_all, tasks_all = sh.reduce_report(elapsed, n_reads_used, n_tasks, dev)
+    rank_ms = elapsed / args.steps * 1e3
+    elapsed, reads_all, tasks_all = sh.reduce_report(elapsed, n_reads_step, n_seeded + n_glb + n_sw, dev)
+    per_rank_ms = [rank_ms]
+    if use_dist:
+        t = torch.zeros(world, dtype=torch.float64, device=dev)
+        t[rank] = rank_ms
+        dist.all_reduce(t)
+        per_rank_ms = [float(x) for x in t.cpu()]
 
-    # ---- secondary measurement: the banded global alignment + traceback kernel (row a2), N=1 only
-    glb = None
-    if world == 1 and args.global_tasks > 0:
-        gpool, gtasks, gwords = tg.generate_global(args.global_tasks, args.workload, seed=11)
-        dg_pool = torch.from_numpy(gpool).to(dev)
-        dg_tasks = torch.from_numpy(gtasks.view(np.uint8)).to(dev)
-        dg_res = torch.zeros(len(gtasks) * pkg.GLB_RES.itemsize, dtype=torch.uint8, device=dev)
-        dg_cig = torch.zeros(gwords + 4, dtype=torch.int32, device=dev)
-        ctx.set_qcap(int(max(gtasks["qlen"].max(), tasks["qlen"].max())))
-        gsteps = max(3, args.steps // 4)
-        with torch.cuda.stream(stream):
-            ctx.global_batch_device(dg_pool.data_ptr(), dg_tasks.data_ptr(), len(gtasks), dg_res.data_ptr(), dg_cig.data_ptr())
-            torch.cuda.synchronize(dev)
-            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            g0.record(stream)
-            for _ in range(gsteps):
-                ctx.global_batch_device(dg_pool.data_ptr(), dg_tasks.data_ptr(), len(gtasks), dg_res.data_ptr(),
-                                        dg_cig.data_ptr())
-            g1.record(stream)
-            torch.cuda.synchronize(dev)
-        ctx.sync()
-        g_ms = g0.elapsed_time(g1) / gsteps
-        gres = dg_res.cpu().numpy().view(pkg.GLB_RES)
-        gcig = dg_cig.cpu().numpy().view(np.uint32)
-        ncores = os.cpu_count() or 1
-        ns = min(len(gtasks), 100000)
-        t1 = time.perf_counter()
-        ores, ocig, ocells = kswlib.orc_global_batch_mt(params, gpool, gtasks[:ns], gwords, nthreads=ncores)
-        t1 = time.perf_counter()
-        ores, ocig, ocells = kswlib.orc_global_batch_mt(params, gpool, gtasks[:ns], gwords, nthreads=ncores)
-        g_cpu_dt = time.perf_counter() - t1
-        ok = bool((ores == gres[:ns]).all())
-        for k in range(0, ns, 97):
-            o, nn = int(gtasks[k]["cigar_off"]), int(ores[k]["n_cigar"])
-            ok = ok and bool((ocig[o:o + nn] == gcig[o:o + nn]).all())
-        band_cells = float((np.minimum(gtasks["qlen"].astype(np.int64), 2 * gtasks["w"].astype(np.int64) + 1)
-                            * gtasks["tlen"].astype(np.int64)).sum())
-        g_bytes = float(gtasks["qlen"].astype(np.int64).sum() + gtasks["tlen"].astype(np.int64).sum()
-                        + 40 * len(gtasks) + 4 * gres["n_cigar"].astype(np.int64).sum())
-        glb = {"kernel": "global_lane_kernel<64|128> (ksw_global2 + traceback, 64 tasks/wave)", "tasks": int(len(gtasks)), "ms": g_ms,
-               "tasks_per_s": len(gtasks) / (g_ms * 1e-3), "band_gcups": band_cells / (g_ms * 1e-3) / 1e9,
-               "algorithmic_GBps": g_bytes / (g_ms * 1e-3) / 1e9, "mean_w": float(gtasks["w"].mean()),
-               "parity": "bit-exact vs oracle (scores, n_cigar, sampled CIGARs)" if ok else "MISMATCH vs oracle",
-               "cpu_port_tasks_per_s": ns / g_cpu_dt, "cpu_threads": ncores}
-        del dg_pool, dg_tasks, dg_res, dg_cig
+    note(f"timed: {rank_ms:.1f} ms per step; instrumented pass")
+    # ---- one more, instrumented pass (untimed): HIP events on the launch streams around every stage and every kernel
+    # of the dominant stage, chunk by chunk
+    stage_ms = {"seed_extension": 0.0, "global_alignment": 0.0, "mate_rescue_sw": 0.0}
+    round_ms = np.zeros(4)
+    gbin_ms = np.zeros(3)
+    for c in ctxs:
+        c.set_kernel_timing(True)
+    evs = []
+    for c in chunks:
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        e[0].record(streams[0]); cx_ext.seedext_batch_device(c["pool"].data_ptr(), c["seeds"].data_ptr(), c["n"], c["sres"].data_ptr()); e[1].record(streams[0])
+        sg = streams[1 % len(streams)]
+        e[2].record(sg); cx_glb.global_batch_device(c["gpool"].data_ptr(), c["gtasks"].data_ptr(), c["ng"], c["gres"].data_ptr(), d_cig.data_ptr()); e[3].record(sg)
+        ss = streams[2 % len(streams)]
+        e[4].record(ss); cx_sw.sw_batch_device(c["spool"].data_ptr(), c["stasks"].data_ptr(), c["ns"], c["swres"].data_ptr()); e[5].record(ss)
+        sync_all()
+        round_ms += np.array(cx_ext.last_seedext_round_ms())
+        gbin_ms += np.maximum(np.array(cx_glb.last_global_bin_ms()), 0.0)
+        evs.append(e)
+    for e in evs:
+        stage_ms["seed_extension"] += e[0].elapsed_time(e[1])
+        stage_ms["global_alignment"] += e[2].elapsed_time(e[3])
+        stage_ms["mate_rescue_sw"] += e[4].elapsed_time(e[5])
+    for c in ctxs:
+        c.set_kernel_timing(False)
 
-    # ---- secondary measurement: mate-rescue local Smith-Waterman (ksw_align2), N=1 only
-    swb = None
-    if world == 1 and args.sw_tasks > 0:
-        spool, stasks = tg.generate_sw(params, args.sw_tasks, args.workload, seed=13)
-        ds_pool = torch.from_numpy(spool).to(dev)
-        ds_tasks = torch.from_numpy(stasks.view(np.uint8)).to(dev)
-        ds_res = torch.zeros(len(stasks) * pkg.SW_RES.itemsize, dtype=torch.uint8, device=dev)
-        ssteps = max(3, args.steps // 4)
-        with torch.cuda.stream(stream):
-            ctx.sw_batch_device(ds_pool.data_ptr(), ds_tasks.data_ptr(), len(stasks), ds_res.data_ptr())
-            torch.cuda.synchronize(dev)
-            s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s0.record(stream)
-            for _ in range(ssteps):
-                ctx.sw_batch_device(ds_pool.data_ptr(), ds_tasks.data_ptr(), len(stasks), ds_res.data_ptr())
-            s1.record(stream)
-            torch.cuda.synchronize(dev)
-        ctx.sync()
-        s_ms = s0.elapsed_time(s1) / ssteps
-        sres = ds_res.cpu().numpy().view(pkg.SW_RES)
-        ncores = os.cpu_count() or 1
-        ns = min(len(stasks), 4000)
-        want, _ = kswlib.orc_sw_batch(params, spool, stasks[:ns], nthreads=ncores)
-        ok = all(bool((want[f] == sres[:ns][f]).all()) for f in kswlib.SW_FIELDS)
-        # cells as the reference visits them: qlen columns x rows of the first pass (all tlen rows unless it stops)
-        # + rows of the reversed pass (te - tb + 1); counted from the results, so it is implementation independent
-        ql, tl = stasks["qlen"].astype(np.int64), stasks["tlen"].astype(np.int64)
-        second = sres["tb"] >= 0
-        cells = float((ql * tl).sum() + ((sres["qe"].astype(np.int64) + 1) * (sres["te"] - sres["tb"] + 1))[second].sum())
-        sw_word = bool((stasks["xtra"] & 0x10000).sum() * 2 < len(stasks))  # KSW_XBYTE absent: ksw_i16's layout
-        sw_cols = int(stasks["qlen"].max())
-        swb = {"kernel": "sw_lane_kernel<%d%s> (ksw_align2 %s mode, 64 tasks/wave, packed u16)"
-                         % (128 if sw_word or sw_cols > 160 else 80 if sw_cols > 80 else 40, ", WORD" if sw_word else "",
-                            "word" if sw_word else "byte"), "tasks": int(len(stasks)),
-               "ms": s_ms, "tasks_per_s": len(stasks) / (s_ms * 1e-3), "gcups": cells / (s_ms * 1e-3) / 1e9,
-               "mean_qlen": float(ql.mean()), "mean_tlen": float(tl.mean()), "rescued": float(second.mean()),
-               "parity": "bit-exact vs oracle (kswr_t, %d sampled tasks)" % ns if ok else "MISMATCH vs oracle"}
-        if kswlib.have_ref():  # the reference's own SSE2 ksw_align2, compiled into oracle/_ref by oracle/Makefile
-            nr = min(len(stasks), 40000)
-            kswlib.ref_sw_batch_mt(params, spool, stasks[:2000], nthreads=ncores)
-            t1 = time.perf_counter()
-            rres = kswlib.ref_sw_batch_mt(params, spool, stasks[:nr], nthreads=ncores)
-            r_dt = time.perf_counter() - t1
-            same = all(bool((rres[f] == sres[:nr][f]).all()) for f in kswlib.SW_FIELDS)
-            swb.update({"cpu_reference_tasks_per_s": nr / r_dt, "cpu_threads": ncores,
-                        "cpu_reference_equal": same, "cpu_sample": "%d tasks, reference ksw_align2 (SSE2) on %d threads" % (nr, ncores)})
-        del ds_pool, ds_tasks, ds_res
-
-    # ---- secondary measurement: FM-index queries of the seeding stage, N=1 only.  The index is
-    # built by the compiled reference (oracle/_ref/bwa index) over a synthetic genome; skipped where oracle/_ref is absent.
-    seedb = None
-    if world == 1 and args.seed_reads > 0:
-        import reflib
-        if reflib.have_ref_bwa() and os.path.exists(os.path.join(kswlib.REF_DIR, "libref_seed_shim.so")):
-            import ctypes as C
-            import tempfile
-            rng = np.random.default_rng(20261010)
-            tmpd = tempfile.mkdtemp(prefix="bmh_seedb_")
-            G = 8_000_000
-            gref = rng.integers(0, 4, G, dtype=np.uint8)
-            fa = os.path.join(tmpd, "ref.fa")
-            reflib.write_fasta(fa, "synth", gref)
-            reflib.build_index(fa)
-            idx = reflib.lib().bwa_idx_load(fa.encode(), 7)
-            prim, L2, sl, words, sai, sa = reflib.bwt_arrays(idx)
-            so = reflib.smem_opt_of(reflib.opt_from_params(params))
-            Lr, nr = 150, args.seed_reads
-            pos = rng.integers(0, G - Lr - 8, size=nr)
-            sreads = gref[pos[:, None] + np.arange(Lr)[None, :]]
-            sub = rng.random(sreads.shape) < 0.02
-            sreads = np.where(sub, (sreads + rng.integers(1, 4, sreads.shape)) & 3, sreads).astype(np.uint8)
-            rcm = rng.random(nr) < 0.5
-            sreads[rcm] = 3 - sreads[rcm][:, ::-1]
-            rl = list(sreads)
-            ctx.set_bwt(prim, L2, sl, words, sai, sa)
-            ctx.smem_batch(so, rl[:2000])
-            got = ctx.smem_batch(so, rl)
-            k_smem = ctx.last_kernel_ms()
-            keep = []
-            cb = kswlib.make_cbwt(prim, L2, sl, words, sai, sa, keep)
-            orc = kswlib.load_oracle()
-            orc.orc_fm_extends.restype = C.c_uint64
-            orc.orc_fm_extends(1)
-            nsmp = min(nr, 2000)
-            okf = True
-            for r in range(nsmp):
-                wc, wi = kswlib.orc_smem_calls(cb, so, rl[r])
-                gc, gi = got[r]
-                okf = okf and len(gc) == len(wc) and len(gi) == len(wi) and bool((gi == wi).all()) and bool((gc["ret"] == wc["ret"]).all())
-            ext_per_read = orc.orc_fm_extends(1) / nsmp
-            iv = np.concatenate([x for _, x in got])
-            sl_ = (iv["info"] & 0xffffffff).astype(np.int64) - (iv["info"] >> 32).astype(np.int64)
-            sel = (sl_ >= int(so["min_seed_len"])) & (iv["x2"] <= 10000)
-            x0s, x2s = iv["x0"][sel].astype(np.int64), iv["x2"][sel].astype(np.int64)
-            ks = (np.repeat(x0s, x2s) + (np.arange(int(x2s.sum()), dtype=np.int64) - np.repeat(np.cumsum(x2s) - x2s, x2s))).astype(np.uint64)
-            ctx.sa_batch(ks[:1000])
-            posg = ctx.sa_batch(ks)
-            k_sa = ctx.last_kernel_ms()
-            shim = C.CDLL(os.path.join(kswlib.REF_DIR, "libref_seed_shim.so"))
-            shim.ref_smem_iter_mt.restype = C.c_uint64
-            ncores = os.cpu_count() or 1
-            spool = np.ascontiguousarray(sreads.reshape(-1))
-            off = np.arange(nr, dtype=np.uint64) * Lr
-            lens = np.full(nr, Lr, dtype=np.int32)
-            cs = C.c_uint64(0)
-            bwt_p = C.c_void_p(idx.contents.bwt)
-            a_ = (bwt_p, C.c_int(nr), spool.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p),
-                  C.c_int(int(so["split_len"])), C.c_int(int(so["split_width"])), C.c_int(int(so["start_width"])), C.c_int(ncores), C.byref(cs))
-            shim.ref_smem_iter_mt(*a_)
-            t1 = time.perf_counter()
-            shim.ref_smem_iter_mt(*a_)
-            cpu_smem = time.perf_counter() - t1
-            posc = np.zeros(len(ks), dtype=np.uint64)
-            shim.ref_sa_mt(bwt_p, ks.ctypes.data_as(C.c_void_p), C.c_int(len(ks)), posc.ctypes.data_as(C.c_void_p), C.c_int(ncores))
-            t1 = time.perf_counter()
-            shim.ref_sa_mt(bwt_p, ks.ctypes.data_as(C.c_void_p), C.c_int(len(ks)), posc.ctypes.data_as(C.c_void_p), C.c_int(ncores))
-            cpu_sa = time.perf_counter() - t1
-            seedb = {"kernel": "smem_kernel (bwt_smem1 in smem_next2 order, one lane per read) + sa_kernel (bwt_sa)",
-                     "genome_bp": G, "reads": nr, "smem_kernel_ms": k_smem, "reads_per_s": nr / (k_smem * 1e-3),
-                     "bwt_extend_per_read": ext_per_read,
-                     "algorithmic_GBps": ext_per_read * 2 * 64.0 * nr / (k_smem * 1e-3) / 1e9, "hbm_frac": ext_per_read * 2 * 64.0 * nr / (k_smem * 1e-3) / 8e12,
-                     "sa_lookups": int(len(ks)), "sa_kernel_ms": k_sa, "sa_lookups_per_s": len(ks) / (k_sa * 1e-3),
-                     "parity": ("bit-exact vs oracle (%d reads) and vs the reference's bwt_sa (all look-ups)" % nsmp)
-                     if okf and bool((posc == posg).all()) else "MISMATCH",
-                     "cpu_reference_reads_per_s": nr / cpu_smem, "cpu_reference_sa_lookups_per_s": len(ks) / cpu_sa, "cpu_threads": ncores}
-
-    # ---- parity spot-check + CPU baseline (untimed w.r.t. the GPU figure)
-    res = d_res.cpu().numpy().view(pkg.EXT_RES)
     out = None
     if rank == 0:
-        ncores = os.cpu_count() or 1
+        note("parity check and CPU baseline")
+        # ---- parity on chunk 0 (its results are still on the device; CIGARs: run its global batch once more) + CPU baseline
+        c0, h0 = chunks[0], host[0]
+        pool, seeds, gpool, gtasks, gwords, spool, stasks = h0
+        cig0 = torch.zeros(gwords + 8, dtype=torch.int32, device=dev)
+        cx_glb.global_batch_device(c0["gpool"].data_ptr(), c0["gtasks"].data_ptr(), c0["ng"], c0["gres"].data_ptr(), cig0.data_ptr())
+        sync_all()
+        sres = c0["sres"].cpu().numpy().view(pkg.SEED_RES)
+        gres = c0["gres"].cpu().numpy().view(pkg.GLB_RES)
+        gcig = cig0.cpu().numpy().view(np.uint32)
+        swres = c0["swres"].cpu().numpy().view(pkg.SW_RES)
+        ns = min(len(seeds), 20000)
+        want, cells, calls = kswlib.orc_seedext_batch(params, pool, seeds[:ns], nthreads=ncores)
+        ok_ext = all(bool((want[f] == sres[:ns][f]).all()) for f in want.dtype.names)
+        cells_per_seed, calls_per_seed = cells / ns, calls / ns
+        ng = min(len(gtasks), 5000)
+        ores, ocig, _ = kswlib.orc_global_batch_mt(params, gpool, gtasks[:ng], gwords, nthreads=ncores)
+        ok_glb = bool((ores == gres[:ng]).all())
+        for k in range(0, ng, 7):
+            o, nn = int(gtasks[k]["cigar_off"]), int(ores[k]["n_cigar"])
+            ok_glb = ok_glb and bool((ocig[o:o + nn] == gcig[o:o + nn]).all())
+        nw = min(len(stasks), 3000)
+        swant, _ = kswlib.orc_sw_batch(params, spool, stasks[:nw], nthreads=ncores)
+        ok_sw = all(bool((swant[f] == swres[:nw][f]).all()) for f in kswlib.SW_FIELDS)
+        parity_ok = ok_ext and ok_glb and ok_sw
+
         cpu = None
-        sample_n = min(n_tasks, 20000)
-        want, cells = kswlib.orc_extend_batch(params, pool, tasks[:sample_n], nthreads=ncores, pac=pac, l_pac=l_pac)
-        parity_ok = bool((want == res[:sample_n]).all())
-        cells_per_task = cells / max(sample_n, 1)
         if world == 1 and not args.no_cpu_baseline:
-            rate = None
+            # the oracle port replaying the SAME records on all host threads: K reads' worth of each stage, sized from a
+            # first pass so that the whole sample costs about --cpu-seconds
             t1 = time.perf_counter()
-            kswlib.orc_extend_batch(params, pool, tasks[:sample_n], nthreads=ncores, pac=pac, l_pac=l_pac)
-            rate = sample_n / (time.perf_counter() - t1)
-            big = int(min(n_tasks, max(sample_n, rate * args.cpu_seconds)))
-            reps = max(1, int(rate * args.cpu_seconds / big))  # whole passes over the sample, ~cpu_seconds in all
+            kswlib.orc_seedext_batch(params, pool, seeds[:ns], nthreads=ncores)
+            kswlib.orc_global_batch_mt(params, gpool, gtasks[:ng], gwords, nthreads=ncores)
+            kswlib.orc_sw_batch(params, spool, stasks[:nw], nthreads=ncores)
+            probe = time.perf_counter() - t1
+            per_read = probe / (ns / (len(seeds) / sizes[0]))  # crude seconds per read of the mix
+            K = int(min(sizes[0], max(20000, args.cpu_seconds / max(per_read, 1e-9) * 0.7)))
+            ke = min(len(seeds), int(K * len(seeds) / sizes[0]))
+            kg = min(len(gtasks), int(K * len(gtasks) / sizes[0]))
+            kw = max(1, min(len(stasks), int(K * len(stasks) / sizes[0])))
             t1 = time.perf_counter()
-            for _ in range(reps):
-                want2, cells2 = kswlib.orc_extend_batch(params, pool, tasks[:big], nthreads=ncores, pac=pac, l_pac=l_pac)
-            dt = time.perf_counter() - t1
-            parity_ok = parity_ok and bool((want2 == res[:big]).all())
-            cells_per_task = cells2 / big
-            reads_in_sample = len(np.unique(tread[:big]))
-            cpu = {"value": reads_in_sample * reps / dt, "unit": "reads/s", "cores": ncores, "kind": "port",
-                   "sample": f"{reps} pass(es) over the first {big} extension tasks ({reads_in_sample} reads) of the "
-                             f"same batch, oracle/ksw_oracle.c on {ncores} pthreads, {dt:.1f} s",
-                   "tasks_per_s": big * reps / dt, "gcups": cells2 * reps / dt / 1e9}
+            w1, cells1, calls1 = kswlib.orc_seedext_batch(params, pool, seeds[:ke], nthreads=ncores)
+            t_e = time.perf_counter() - t1
+            t1 = time.perf_counter()
+            g1, gc1, _ = kswlib.orc_global_batch_mt(params, gpool, gtasks[:kg], gwords, nthreads=ncores)
+            t_g = time.perf_counter() - t1
+            t1 = time.perf_counter()
+            s1, _ = kswlib.orc_sw_batch(params, spool, stasks[:kw], nthreads=ncores)
+            t_s = time.perf_counter() - t1
+            parity_ok = parity_ok and all(bool((w1[f] == sres[:ke][f]).all()) for f in w1.dtype.names) and bool((g1 == gres[:kg]).all()) \
+                and all(bool((s1[f] == swres[:kw][f]).all()) for f in kswlib.SW_FIELDS)
+            cells_per_seed, calls_per_seed = cells1 / ke, calls1 / ke
+            cpu = {"value": K / (t_e + t_g + t_s), "unit": "reads/s", "cores": ncores, "kind": "port",
+                   "sample": f"the first {K} reads' worth of chunk 0 of the same step ({ke} fused seed extensions, {kg} global alignments, "
+                             f"{kw} mate-rescue Smith-Watermans) replayed by oracle/*.c on {ncores} pthreads: "
+                             f"{t_e:.2f} + {t_g:.2f} + {t_s:.2f} s; every result compared with the GPU's",
+                   "cores_note": cores_note,
+                   "stage_seconds": {"seed_extension": t_e, "global_alignment": t_g, "mate_rescue_sw": t_s}}
+
         ms_per_step = elapsed / args.steps * 1e3
         value = reads_all * args.steps / elapsed
-        # dominant kernel = the length bin that takes the most time; its algorithmic bytes / its duration
-        mode = os.environ.get("BMH_EXT_MODE", "lane")
-        fam = {"lane": ["extend_lane_kernel<32> (qlen<=32, 64 tasks/wave)", "extend_lane_kernel<64> (qlen<=64, 64 tasks/wave)",
-                        "extend_lane_kernel<128> (qlen<=128, 64 tasks/wave)"],
-               "grp": ["extend_grp_kernel<2> (qlen<=32, 4 tasks/wave)", "extend_grp_kernel<4> (qlen<=64, 4 tasks/wave)",
-                       "extend_grp_kernel<8> (qlen<=128, 4 tasks/wave)"],
-               "reg": ["extend_reg_kernel<1> (qlen<=32)", "extend_reg_kernel<1> (qlen<=64)", "extend_reg_kernel<2> (qlen<=128)"],
-               "lds": ["-", "-", "-"]}[mode if mode != "lanex4" else "lane"]
-        bin_names = fam + (["extend_lanex_kernel<2> (qlen<=256, 32 tasks/wave)", "extend_lanex_kernel<4> (qlen<=512, 16 tasks/wave)"]
-                           if mode in ("lane", "lanex4") else ["extend_reg_kernel<4> (qlen<=256)", "-"]) + ["extend_lds_kernel (longer)"]
-        ql = tasks["qlen"].astype(np.int64)
-        tl = tasks["tlen"].astype(np.int64)
-        which = np.where(ql < 1, 5, np.where(ql <= 32, 0, np.where(ql <= 64, 1, np.where(ql <= 128, 2, np.where(
-            ql <= 256, 3, np.where((ql <= 512) & (mode == "lanex4"), 4, 5))))))
-        if mode == "grp":
-            which = np.where((ql >= 1) & (ql <= 256) & (tl > 1024), 3, which)
-        if mode == "lds":
-            which[:] = 5
-        per_task_bytes = ql + tasks["tlen"].astype(np.int64) + 56  # qlen + tlen + 32 + 24
+        # ---- kernels of the step (instrumented pass): the fused extension's four rounds, the three global kernels, the SW stage
+        ql, tl, gw = (np.concatenate([h[3][f].astype(np.int64) for h in host]) for f in ("qlen", "tlen", "w"))
+        worst = int(params["o_del"]) + int(params["o_ins"]) + max(int(params["e_del"]), int(params["e_ins"])) * (ql + tl) + \
+            max(int(-params["mat"].min()), int(params["mat"].max())) * np.maximum(ql, tl)
+        lane_ok = (tl <= 512) & (worst < 12000)
+        gbin = np.where(lane_ok & (gw <= 31), 0, np.where(lane_ok & (gw <= 63), 1, 2))
+        g_ncig_mean = float(gres["n_cigar"].mean())
+        g_bytes = ql + tl + 40 + 4 * g_ncig_mean  # qlen + tlen + 32 + 8 + 4*n_cigar
+        seeds_all_q = np.concatenate([h[1]["l_query"].astype(np.int64) for h in host])
+        seeds_all_w = np.concatenate([h[1]["wlen"].astype(np.int64) for h in host])
+        ext_bytes = float((seeds_all_q + seeds_all_w).sum() + n_seeded * (40 + 32))  # read + window + the 40 B record + 32 B result
+        sw_bytes = float(sum((h[6]["qlen"].astype(np.int64) + h[6]["tlen"].astype(np.int64)).sum() + 64 * len(h[6]) for h in host))
         kernels = []
-        for b in range(6):
-            nb = int((which == b).sum())
-            if nb == 0:
-                continue
-            bb = int(per_task_bytes[which == b].sum())
-            kernels.append({"kernel": bin_names[b], "tasks": nb, "ms": bin_ms[b], "algorithmic_bytes": bb,
-                            "GBps": bb / (bin_ms[b] * 1e-3) / 1e9 if bin_ms[b] > 0 else None})
+        names = ["round L1: left extensions (extend_lane_kernel<32|64|128> + seed_left_make)", "round L2: left retries at 2w",
+                 "round R1: right extensions, h0 = the device's left score", "round R2: right retries at 2w"]
+        for k in range(4):
+            kernels.append({"kernel": "seedext " + names[k], "ms": float(round_ms[k]), "launches": n_chunks,
+                            "algorithmic_bytes": ext_bytes / 2 if k in (0, 2) else 0.0})
+        gnames = ["global_lane_kernel<64> (ksw_global2 + traceback, w <= 31, 64 tasks/wave)", "global_lane_kernel<128> (w <= 63)",
+                  "global_kernel (one wave per task: wide bands, long targets)"]
+        for b in range(3):
+            kernels.append({"kernel": gnames[b], "ms": float(gbin_ms[b]), "launches": n_chunks, "tasks": int((gbin == b).sum()),
+                            "algorithmic_bytes": float(g_bytes[gbin == b].sum())})
+        kernels.append({"kernel": "sw_lane_kernel<80> + second pass (ksw_align2, mate rescue)", "ms": stage_ms["mate_rescue_sw"], "launches": n_chunks,
+                        "tasks": n_sw, "algorithmic_bytes": sw_bytes})
+        for k in kernels:
+            k["avg_launch_ms"] = k["ms"] / k["launches"]
+            k["GBps"] = k["algorithmic_bytes"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else None
         dom = max(kernels, key=lambda k: k["ms"])
-        ach = dom["GBps"]
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):  # HBM bytes per launch from rocprofv3 PMC passes of this same command
+        traffic_src = None
+        if os.path.exists(tpath):  # HBM bytes per launch from rocprofv3 PMC passes of this same command (tools/profile_bench.sh)
             tj = json.load(open(tpath))
-            for k, v in tj.get("kernels", {}).items():
-                if dom["kernel"].split(" ")[0].rstrip(">") in k:  # e.g. "extend_lane_kernel<128" in "bmh::extend_lane_kernel<128, true>"
+            key = dom["kernel"].split(" ")[0]
+            for kname, v in tj.get("kernels", {}).items():
+                if key.rstrip(">") in kname:
                     traffic = v.get("hbm_bytes_per_launch")
-        # `metric` is BASELINE.json's, verbatim; what is timed is named in config.workload (BASELINE.json configs[1]: the
-        # hg38 configurations need an index this image cannot build, SURVEY.md §8d replaces them by the task generator)
+                    traffic_src = f"profiles/traffic_latest.json ({tj.get('commit', 'commit not recorded')}; rocprofv3 FETCH_SIZE+WRITE_SIZE passes of this command)"
         metric = "aligned reads/sec (150 bp PE vs hg38) at 1/2/4/8 MI355X; SAM bit-exact vs CPU"
         bpath = os.path.join(ROOT, "BASELINE.json")
         if os.path.exists(bpath):
             metric = json.load(open(bpath)).get("metric", metric)
+        step_cells = cells_per_seed * n_seeded
         out = {
             "metric": metric,
             "value": value, "unit": "reads/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int32", "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[1] shape: {args.reads} x {args.workload} synthetic SE reads per GPU per step -> "
-                                   f"the ksw_extend2 tasks mem_chain2aln builds for them (taskgen.c, SURVEY.md §8d), extension hot path "
-                                   f"on the GPU; results checked bit-exact against the oracle after timing (the tasks the CPU baseline replays -- the whole batch "
-                                   f"on a 256-thread box -- or 20 000 without it)",
-                       "reads_per_gpu": args.reads, "tasks_per_gpu": n_tasks,
-                       "mean_qlen": float(tasks["qlen"].mean()), "mean_tlen": float(tasks["tlen"].mean()),
-                       "target_source": args.target_source, "parallelism": f"static shard x{world}, no collective"},
+            "dtype": "int16", "data": "synthetic",
+            "config": {"workload": f"pe10m -- BASELINE.json configs[2]: {args.pairs} x 2 x {args.shape} read pairs per GPU per step through the whole DP path "
+                                   f"(fused seed extension with the right extension started from the device's left score, ksw_global2 + traceback, "
+                                   f"mate-rescue ksw_align2), task generator in place of the hg38 index (SURVEY.md §8d), streamed in {n_chunks} chunks, "
+                                   f"inputs resident in HBM; seeding, chaining and SAM text are host stages outside the step (see cpu_baseline_pipeline)",
+                       "pairs_per_gpu": args.pairs, "reads_per_gpu": n_reads_step, "chunks": n_chunks, "seeded_reads_per_gpu": n_seeded,
+                       "ksw_extend2_calls_per_gpu": int(round(calls_per_seed * n_seeded)), "global_tasks_per_gpu": n_glb, "rescue_tasks_per_gpu": n_sw,
+                       "mean_global_w": float(gw.mean()), "streams": args.streams,
+                       "parallelism": f"static shard x{world}, one process per GPU, no collective on the data path"},
             "tasks_per_s": tasks_all * args.steps / elapsed,
-            "gcups": cells_per_task * tasks_all * args.steps / elapsed / 1e9,
-            "parity": "bit-exact vs oracle on sampled tasks" if parity_ok else "MISMATCH vs oracle",
-            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": dom["kernel"], "kernel_ms": dom["ms"],
-                         "algorithmic_bytes_per_launch": dom["algorithmic_bytes"],
-                         "step_kernels_ms": step_kernels_ms, "kernels": kernels,
-                         "note": "integer max-plus DP: VALU-issue bound, not HBM bound (~220 int-ops per "
-                                 "algorithmic byte vs ~5 ops/B machine balance, SURVEY.md §8d); the HBM fraction "
-                                 "is reported because the contract asks for it, GCUPS is the honest figure"},
+            "per_rank_ms_per_step": per_rank_ms,
+            "parity": ("bit-exact vs oracle: fused seed extensions, global alignments (scores, n_cigar, sampled CIGARs), mate-rescue SW"
+                       if parity_ok else f"MISMATCH vs oracle (ext {ok_ext}, global {ok_glb}, sw {ok_sw})"),
+            "stages_ms_per_step": {k: v for k, v in stage_ms.items()},
+            "stage_rates": {"seed_extension_gcups": step_cells / (stage_ms["seed_extension"] * 1e-3) / 1e9,
+                            "ksw_extend2_per_s": calls_per_seed * n_seeded / (stage_ms["seed_extension"] * 1e-3),
+                            "global_tasks_per_s": n_glb / (stage_ms["global_alignment"] * 1e-3),
+                            "rescue_tasks_per_s": n_sw / (stage_ms["mate_rescue_sw"] * 1e-3)},
+            "roofline": {"bound": "hbm", "bound_measured": "valu-issue (integer max-plus DP, no MFMA form)", "achieved": dom["GBps"], "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": (dom["GBps"] or 0.0) / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": dom["kernel"], "kernel_ms": dom["avg_launch_ms"],
+                         "algorithmic_bytes_per_launch": dom["algorithmic_bytes"] / dom["launches"], "kernels": kernels,
+                         "note": "achieved = algorithmic bytes of the dominant kernel's tasks / its HIP-event duration (instrumented pass, "
+                                 "events on the launch stream); integer DP is VALU-issue bound, GCUPS / tasks/s are the honest figures"},
             "cpu_baseline": cpu,
-            "global_alignment": glb,
-            "mate_rescue_sw": swb,
-            "seeding_fmindex": seedb,
-            "setup": {"taskgen_s": gen_s},
+            "cpu_baseline_pipeline": pipe,
+            "setup": {"taskgen_s": gen_s, "upload_s": upload_s, "host_threads_for_generation": workers},
         }
         if not parity_ok:
             out["value"] = 0.0  # a fast kernel with different results is not done
@@ -412,7 +472,8 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
-    ctx.close()
+    for c in ctxs:
+        c.close()
 
 
 if __name__ == "__main__":

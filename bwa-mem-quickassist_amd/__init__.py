@@ -117,6 +117,7 @@ def lib():
         L.bmh_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.bmh_last_extend_bin_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.bmh_last_global_bin_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.bmh_last_seedext_round_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.bmh_upload_pool.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.bmh_extend_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int64, C.c_void_p]
         L.bmh_extend_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
@@ -220,6 +221,11 @@ class Context:
     def last_extend_bin_ms(self):
         ms = (C.c_float * 6)()
         self._check(lib().bmh_last_extend_bin_ms(self._h, ms))
+        return [float(x) for x in ms]
+
+    def last_seedext_round_ms(self):
+        ms = (C.c_float * 4)()
+        self._check(lib().bmh_last_seedext_round_ms(self._h, ms))
         return [float(x) for x in ms]
 
     def last_global_bin_ms(self):

@@ -188,6 +188,11 @@ int bmh_ctx_create(bmh_ctx_t **out, int device)
 			bmh_ctx_destroy(ctx);
 			return BMH_E_NODEVICE;
 		}
+	for (int b = 0; b < 5; ++b)
+		if (hipEventCreate(&ctx->ev_sround[b]) != hipSuccess) {
+			bmh_ctx_destroy(ctx);
+			return BMH_E_NODEVICE;
+		}
 	for (int b = 0; b < 4; ++b)
 		if (hipEventCreate(&ctx->ev_gbin[b]) != hipSuccess) {
 			bmh_ctx_destroy(ctx);
@@ -239,6 +244,8 @@ int bmh_ctx_destroy(bmh_ctx_t *ctx)
 	}
 	for (int b = 0; b < 4; ++b)
 		if (ctx->ev_gbin[b]) (void)hipEventDestroy(ctx->ev_gbin[b]);
+	for (int b = 0; b < 5; ++b)
+		if (ctx->ev_sround[b]) (void)hipEventDestroy(ctx->ev_sround[b]);
 	if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
 	if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
 	if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
@@ -386,6 +393,16 @@ int bmh_last_extend_bin_ms(bmh_ctx_t *ctx, float ms[6])
 	if (!ctx->ev_bin_valid) return BMH_OK;
 	BMH_HIP(ctx, hipEventSynchronize(ctx->ev1)); // recorded after both streams joined
 	for (int b = 0; b < kExtBins; ++b) BMH_HIP(ctx, hipEventElapsedTime(&ms[b], ctx->ev_bin[b], ctx->ev_bin_end[b]));
+	return BMH_OK;
+}
+
+int bmh_last_seedext_round_ms(bmh_ctx_t *ctx, float ms[4])
+{
+	if (!ctx || !ms) return BMH_E_ARG;
+	ms[0] = ms[1] = ms[2] = ms[3] = -1.f;
+	if (!ctx->ev_sround_valid) return BMH_OK;
+	BMH_HIP(ctx, hipEventSynchronize(ctx->ev_sround[4]));
+	for (int b = 0; b < 4; ++b) BMH_HIP(ctx, hipEventElapsedTime(&ms[b], ctx->ev_sround[b], ctx->ev_sround[b + 1]));
 	return BMH_OK;
 }
 

@@ -57,6 +57,8 @@ struct bmh_ctx {
 	bool ev_bin_valid = false;
 	hipEvent_t ev_gbin[4] = {}; // boundaries of the three kernels of a global-alignment launch (64-slot, 128-slot, wave)
 	bool ev_gbin_valid = false;
+	hipEvent_t ev_sround[5] = {}; // boundaries of the four rounds of a fused per-seed launch
+	bool ev_sround_valid = false;
 	std::string last_error;
 	bmh_driver_stats_t dstats{};
 	int ncu = 256; // compute units of the device (persistent grids are sized from it)

@@ -221,17 +221,29 @@ int launch_seedext(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_seed_task_t *d
 	const SeedP sp = {ctx->params.a, ctx->params.w, ctx->params.pen_clip5, ctx->params.pen_clip3, ctx->dev.max_mat};
 	const unsigned grid = (unsigned)((n + 255) / 256);
 	hipStream_t s = ctx->stream;
+	const bool tm = ctx->timing;
+#define BMH_SROUND(k)                                                   \
+	do {                                                                \
+		if (tm) BMH_HIP(ctx, hipEventRecord(ctx->ev_sround[k], s));     \
+	} while (0)
 	BMH_HIP(ctx, hipMemsetAsync(ws.cnt, 0, 64, s));
+	BMH_SROUND(0);
 	hipLaunchKernelGGL(seed_left_make, dim3(grid), dim3(256), 0, s, d_tasks, (long long)n, sp, ws.T, ws.L, ws.cnt, ws.ST, ctx->d_err);
 	if ((rc = launch_extend(ctx, d_pool, ws.T, n, ws.X, ws.L, qmax, ws.cnt + 0, 1))) return rc;
+	BMH_SROUND(1);
 	hipLaunchKernelGGL(seed_try<false>, dim3(grid), dim3(256), 0, s, d_tasks, (long long)n, sp, ws.T, ws.X, ws.T2, ws.cnt, ws.ST);
 	if ((rc = launch_extend(ctx, d_pool, ws.T2, n, ws.X2, nullptr, qmax, ws.cnt + 1, 2))) return rc;
+	BMH_SROUND(2);
 	hipLaunchKernelGGL(seed_right_make, dim3(grid), dim3(256), 0, s, d_tasks, (long long)n, sp, ws.X, ws.X2, ws.T, ws.L, ws.cnt, ws.ST,
 	                   d_res);
 	if ((rc = launch_extend(ctx, d_pool, ws.T, n, ws.X, ws.L, qmax, ws.cnt + 2, 3))) return rc;
+	BMH_SROUND(3);
 	hipLaunchKernelGGL(seed_try<true>, dim3(grid), dim3(256), 0, s, d_tasks, (long long)n, sp, ws.T, ws.X, ws.T2, ws.cnt, ws.ST);
 	if ((rc = launch_extend(ctx, d_pool, ws.T2, n, ws.X2, nullptr, qmax, ws.cnt + 3, 4))) return rc;
 	hipLaunchKernelGGL(seed_finish, dim3(grid), dim3(256), 0, s, d_tasks, (long long)n, sp, ws.X, ws.X2, ws.ST, d_res);
+	BMH_SROUND(4);
+#undef BMH_SROUND
+	if (tm) ctx->ev_sround_valid = true;
 	BMH_HIP(ctx, hipGetLastError());
 	return BMH_OK;
 }

@@ -111,8 +111,6 @@ extern bmh_chain_v mem_chain(const void *opt, const void *bwt, int64_t l_pac, in
 extern int mem_chain_flt(const void *opt, int n_chn, bmh_chain_t *chains);
 extern int mem_chain2aln_short(const void *opt, int64_t l_pac, const uint8_t *pac, int l_query, const uint8_t *query,
                                const bmh_chain_t *c, bmh_alnreg_v *av);
-extern int mem_sort_and_dedup(int n, bmh_alnreg_t *a, float mask_level_redun);
-extern int mem_test_and_remove_exact(const void *opt, int n, bmh_alnreg_t *a, int qlen);
 extern unsigned char nst_nt4_table[256];
 extern double cputime(void), realtime(void); /* utils.c */
 
@@ -356,12 +354,14 @@ bmh_alnreg_v *mem_align1_core_batched(const ref_mem_opt_t *opt, const void *bwt,
 		}
 	}
 
-	for (b = 0; b < batch_size; ++b) { /* CPU stages after the path, unchanged: bwamem.c:1106,1112-1117 */
+	for (b = 0; b < batch_size; ++b) { /* host stages after the path: bwamem.c:1106,1112-1117 */
 		for (i = 0; i < (int)chn[b].n; ++i) free(chn[b].a[i].seeds);
 		free(chn[b].a);
-		regs[b].n = (size_t)mem_sort_and_dedup((int)regs[b].n, regs[b].a, opt->mask_level_redun);
-		if (opt->flag & REF_MEM_F_NO_EXACT)
-			regs[b].n = (size_t)mem_test_and_remove_exact(opt, (int)regs[b].n, regs[b].a, seqs[start + b].l_seq);
+		regs[b].n = (size_t)bmh_sort_and_dedup((int)regs[b].n, regs[b].a, opt->mask_level_redun); /* bwamem.c:1114 */
+		if ((opt->flag & REF_MEM_F_NO_EXACT) && regs[b].n && regs[b].a[0].truesc == seqs[start + b].l_seq * opt->a) { /* mem_test_and_remove_exact, bwamem.c:438-443 */
+			memmove(regs[b].a, regs[b].a + 1, (regs[b].n - 1) * sizeof(bmh_alnreg_t));
+			--regs[b].n;
+		}
 	}
 	free(chn);
 	free(reads);
@@ -370,14 +370,13 @@ bmh_alnreg_v *mem_align1_core_batched(const ref_mem_opt_t *opt, const void *bwt,
 
 /* =====================================================================================================================
  * mem_process_seqs() with the reference's exact signature (bwamem.h:117, bwamem.c:1297-1327): the same three steps as
- * the reference -- phase 1 through the batching seam above, insert-size statistics, phase 2 -- with TWO additions
- * between them, each one GPU-batched call for the whole chunk:
- *   (1) pairs: mate rescue (bmh_matesw_batch), after which phase 2 runs with MEM_F_NO_RESCUE so that mem_sam_pe skips
- *       its own per-pair rescue block (bwamem_pair.c:251-263) and goes on with the vectors the batch left -- which
- *       are, element for element, what that block would have produced;            BMH_MATESW_BATCH=0 turns it off
- *   (2) the global alignments of phase 2 (bmh_reg2cigar_batch), served to mem_reg2aln through an interposed
- *       bwa_gen_cigar2 (below);                                                    BMH_CIGAR_BATCH=0 turns it off
- * With both off the call is forwarded to the reference's own mem_process_seqs.
+ * the reference -- phase 1 through the batching seam above, insert-size statistics, phase 2 -- every data-parallel part
+ * of them as GPU batches and the host code between them the library's own:
+ *   phase 1   mem_align1_core_batched above (seeding batch, chaining, bmh_chain2aln_batch, bmh_sort_and_dedup)
+ *   pairs     bmh_pestat, then the whole chunk's mate rescue (bmh_matesw_batch, one slice per GPU place)
+ *   phase 2   bmh_sam_batch per slice of the chunk: primary marking, pairing, the global alignments of exactly the
+ *             regions that get printed (bmh_reg2cigar_batch), SAM text
+ * Nothing of the reference's bwamem.c / bwamem_pair.c runs after chaining.
  */
 
 #define REF_MEM_F_PE 0x2         /* bwamem.h:14 */
@@ -385,20 +384,16 @@ bmh_alnreg_v *mem_align1_core_batched(const ref_mem_opt_t *opt, const void *bwt,
 
 extern void kt_for(int n_threads, void (*func)(void *, int, int), void *data, int n);                       /* kthread.c */
 extern void kt_for_batch(int n_threads, void (*func)(void *, int, int, int), void *data, int n, int batch);  /* kthread_batch.c:44 */
-extern void mem_pestat(const void *opt, int64_t l_pac, int n, const bmh_alnreg_v *regs, bmh_pestat_t pes[4]); /* bwamem_pair.c:46 */
-extern int mem_sam_pe(const void *opt, const void *bns, const uint8_t *pac, const bmh_pestat_t pes[4], uint64_t id,
-                      ref_bseq1_t s[2], bmh_alnreg_v a[2]);                                                 /* bwamem_pair.c:238 */
 extern int bwa_verbose;
+extern char bwa_rg_id[256]; /* bwa.c:16 */
 
 typedef struct {
 	const ref_mem_opt_t *opt;
 	const void *bwt;
 	const ref_bntseq_head_t *bns;
 	const uint8_t *pac;
-	const bmh_pestat_t *pes;
 	ref_bseq1_t *seqs;
 	bmh_alnreg_v *regs;
-	int64_t n_processed;
 } qa_worker_t;
 
 static void qa_worker1_batched(void *data, int start, int batch_size, int tid) /* == worker1_batched, bwamem.c:1264-1279 */
@@ -411,103 +406,22 @@ static void qa_worker1_batched(void *data, int start, int batch_size, int tid) /
 	free(ret);
 }
 
-static void qa_worker2_pe(void *data, int i, int tid) /* == the PE branch of worker2, bwamem.c:1290-1294 */
+static int qa_dedup(void *user, int n, bmh_alnreg_t *a) /* bmh_dedup_fn of the mate-rescue driver */
 {
-	qa_worker_t *w = (qa_worker_t *)data;
-	(void)tid;
-	mem_sam_pe(w->opt, w->bns, w->pac, w->pes, (uint64_t)(w->n_processed >> 1) + (uint64_t)i, &w->seqs[i << 1], &w->regs[i << 1]);
-	free(w->regs[i << 1 | 0].a), free(w->regs[i << 1 | 1].a);
+	return bmh_sort_and_dedup(n, a, ((const ref_mem_opt_t *)user)->mask_level_redun);
 }
 
-static int qa_dedup(void *user, int n, bmh_alnreg_t *a) /* bmh_dedup_fn over the reference's own function */
-{
-	return mem_sort_and_dedup(n, a, ((const ref_mem_opt_t *)user)->mask_level_redun);
-}
-
-/* ---- phase 2's global alignments for the whole chunk in one go ------------------------------------------------------
- * mem_reg2aln (bwamem.c:1164-1236) is called per region from inside reference code (mem_reg2sam_se, mem_sam_pe) and is
- * not worth restating; what it spends its time in is the loop over bwa_gen_cigar2 (bwamem.c:1193-1201).  So the shim
- * computes that loop's FINAL outcome for every region of the chunk up front with bmh_reg2cigar_batch (<= 3 GPU rounds of
- * ksw_global2) and serves it from a table through an interposed bwa_gen_cigar2 (bwa.h:35): the loop calls it, gets the
- * final CIGAR+MD/score/NM at once, and -- if it asks again because score < truesc - a -- receives the same answer, sees
- * `score == last_sc` and stops (bwamem.c:1197), i.e. it ends in exactly the state the reference ends in.  A call that is
- * not in the table (bwa_fix_xref2's internal one, other sub-commands) goes to the reference's own bwa_gen_cigar2. */
-extern int bwa_fix_xref2(const int8_t mat[25], int o_del, int e_del, int o_ins, int e_ins, int w, const void *bns,
-                         const uint8_t *pac, uint8_t *query, int *qb, int *qe, int64_t *rb, int64_t *re); /* bwa.c:179 */
-extern void mem_mark_primary_se(const void *opt, int n, bmh_alnreg_t *a, int64_t id);                      /* bwamem.c:904 */
-extern void mem_reg2sam_se(const void *opt, const void *bns, const uint8_t *pac, ref_bseq1_t *s, bmh_alnreg_v *a,
-                           int extra_flag, const void *m);                                                 /* bwamem.c:1049 */
-
-typedef struct {
-	const uint8_t *q; /* the query bytes the entry was computed for (inside the chunk's reads) */
-	int32_t l, score, n_cigar, NM;
-	int64_t rb, re;
-	const uint32_t *cigar;
-	const char *md;
-	uint32_t md_len, used;
-} cg_entry_t;
-typedef struct { /* one slice of the chunk = one bmh_reg2cigar_batch call on one host thread */
-	size_t n_req;
-	bmh_cigar_req_t *reqs;
-	bmh_cigar_res_t *res;
-	uint32_t *cig;
-	char *md;
-} cg_slice_t;
-static struct {
-	cg_entry_t *tab; /* read-only while phase 2 runs */
-	size_t cap;
-	cg_slice_t *slices;
-	int n_slices;
-	long long hits, misses;
-} g_cg;
-
-static size_t cg_hash(int l, int64_t rb, int64_t re)
-{
-	uint64_t h = (uint64_t)rb * 0x9e3779b97f4a7c15ULL ^ (uint64_t)re * 0xc2b2ae3d27d4eb4fULL ^ (uint64_t)l * 0x165667b19e3779f9ULL;
-	return (size_t)(h ^ h >> 29);
-}
-
-typedef uint32_t *(*gen_cigar2_fn)(const int8_t *, int, int, int, int, int, int64_t, const uint8_t *, int, uint8_t *, int64_t,
-                                   int64_t, int *, int *, int *);
-
-uint32_t *bwa_gen_cigar2(const int8_t mat[25], int o_del, int e_del, int o_ins, int e_ins, int w_, int64_t l_pac,
-                         const uint8_t *pac, int l_query, uint8_t *query, int64_t rb, int64_t re, int *score, int *n_cigar,
-                         int *NM)
-{
-	static gen_cigar2_fn next;
-	if (g_cg.tab && l_query > 0) {
-		size_t k = cg_hash(l_query, rb, re) & (g_cg.cap - 1);
-		for (; g_cg.tab[k].used; k = (k + 1) & (g_cg.cap - 1)) {
-			const cg_entry_t *e = &g_cg.tab[k];
-			if (e->l == l_query && e->rb == rb && e->re == re && memcmp(e->q, query, (size_t)l_query) == 0) {
-				uint32_t *out = (uint32_t *)malloc(4 * (size_t)e->n_cigar + e->md_len + 1); /* CIGAR, then MD (bwa.c:136,161-163) */
-				memcpy(out, e->cigar, 4 * (size_t)e->n_cigar);
-				memcpy((char *)(out + e->n_cigar), e->md, (size_t)e->md_len + 1);
-				*score = e->score, *n_cigar = e->n_cigar, *NM = e->NM;
-				__sync_fetch_and_add(&g_cg.hits, 1);
-				return out;
-			}
-		}
-		__sync_fetch_and_add(&g_cg.misses, 1);
-	}
-	if (!next) next = (gen_cigar2_fn)dlsym(RTLD_NEXT, "bwa_gen_cigar2");
-	if (!next) bmh_tls_die("no other bwa_gen_cigar2 is loaded", BMH_E_ARG);
-	return next(mat, o_del, e_del, o_ins, e_ins, w_, l_pac, pac, l_query, query, rb, re, score, n_cigar, NM);
-}
-
-/* every region phase 2 may turn into an alignment: score >= T (mem_reg2sam_se :1060; the pairing code picks from the same
- * vectors).  Secondary marks are not known yet, so this is a superset; the extra alignments are cheap on the GPU.
- * The chunk is cut into one slice per host thread: each runs its own bmh_reg2cigar_batch on its thread-local context
- * (band inference, NM and MD are host work and scale with the threads; the GPU batches of the slices overlap). */
 typedef struct {
 	const ref_mem_opt_t *opt;
 	const ref_bntseq_head_t *bns;
 	const uint8_t *pac;
 	int n, n_slices;
+	int64_t n_processed;
 	ref_bseq1_t *seqs;
 	bmh_alnreg_v *regs;
 	const bmh_read_t *reads;
 	const bmh_params_t *params;
+	const bmh_sam_opt_t *sopt;
 	const bmh_pestat_t *pes;
 	int resident;
 } qa_slice_job_t;
@@ -518,91 +432,6 @@ static bmh_ctx_t *qa_slice_ctx(const qa_slice_job_t *J)
 	int rc;
 	if (J->resident && (rc = bmh_ctx_set_pac(ctx, J->pac, J->bns->l_pac))) bmh_tls_die(bmh_last_error(ctx), rc);
 	return ctx;
-}
-
-static void qa_cigar_slice(void *data, int k, int tid)
-{
-	const qa_slice_job_t *J = (const qa_slice_job_t *)data;
-	const ref_mem_opt_t *opt = J->opt;
-	cg_slice_t *S = &g_cg.slices[k];
-	const int lo = (int)((int64_t)J->n * k / J->n_slices), hi = (int)((int64_t)J->n * (k + 1) / J->n_slices);
-	size_t n_req = 0, cw = 8, mb = 16;
-	int i, rc;
-	(void)tid;
-	for (i = lo; i < hi; ++i) n_req += J->regs[i].n;
-	if (n_req == 0) return;
-	S->reqs = (bmh_cigar_req_t *)malloc(sizeof(*S->reqs) * n_req), n_req = 0;
-	for (i = lo; i < hi; ++i) {
-		size_t j;
-		for (j = 0; j < J->regs[i].n; ++j) {
-			const bmh_alnreg_t *ar = &J->regs[i].a[j];
-			int qb = ar->qb, qe = ar->qe;
-			int64_t rb = ar->rb, re = ar->re;
-			bmh_cigar_req_t *q;
-			if (ar->score < opt->T || rb < 0 || re < 0) continue;
-			if (bwa_fix_xref2(opt->mat, opt->o_del, opt->e_del, opt->o_ins, opt->e_ins, opt->w, J->bns, J->pac, (uint8_t *)J->seqs[i].seq,
-			                  &qb, &qe, &rb, &re) < 0)
-				continue; /* the reference aborts on this region (bwamem.c:1183-1186); let it */
-			if (qe <= qb || re <= rb) continue;
-			q = &S->reqs[n_req++];
-			q->read = i, q->qb = qb, q->qe = qe, q->rb = rb, q->re = re, q->truesc = ar->truesc, q->reg_w = ar->w;
-			cw += (size_t)(qe - qb) + (size_t)(re - rb) + 2, mb += 3 * ((size_t)(qe - qb) + (size_t)(re - rb)) + 16;
-		}
-	}
-	if (n_req == 0) return;
-	S->n_req = n_req;
-	S->res = (bmh_cigar_res_t *)malloc(sizeof(*S->res) * n_req);
-	S->cig = (uint32_t *)malloc(4 * cw), S->md = (char *)malloc(mb);
-	{
-		bmh_ctx_t *ctx;
-		gpu_enter();
-		ctx = qa_slice_ctx(J);
-		if ((rc = bmh_reg2cigar_batch(ctx, J->bns->l_pac, J->pac, J->reads, (int64_t)n_req, S->reqs, S->res, S->cig, cw, S->md, mb)))
-			bmh_tls_die(bmh_last_error(ctx), rc);
-		bmh_pool_put(ctx);
-		gpu_leave();
-	}
-	{ /* into the chunk's table, from this slice's thread (a slot is claimed with a compare-and-swap; nobody reads the table
-	   * before every slice is done) */
-		size_t j;
-		for (j = 0; j < S->n_req; ++j) {
-			const bmh_cigar_req_t *q = &S->reqs[j];
-			cg_entry_t *e;
-			size_t h;
-			if (S->res[j].NM < 0) continue; /* rejected (bwa.c:99): leave it to the reference */
-			for (h = cg_hash(q->qe - q->qb, q->rb, q->re) & (g_cg.cap - 1); !__sync_bool_compare_and_swap(&g_cg.tab[h].used, 0u, 1u);
-			     h = (h + 1) & (g_cg.cap - 1)) {}
-			e = &g_cg.tab[h];
-			e->q = J->reads[q->read].seq + q->qb, e->l = q->qe - q->qb, e->rb = q->rb, e->re = q->re;
-			e->score = S->res[j].score, e->n_cigar = S->res[j].n_cigar, e->NM = S->res[j].NM;
-			e->cigar = S->cig + S->res[j].cigar_off, e->md = S->md + S->res[j].md_off, e->md_len = S->res[j].md_len;
-		}
-	}
-}
-
-static void qa_cigar_cache_build(qa_slice_job_t *J, int n_threads)
-{
-	size_t total = 0, ub = 0;
-	int s, i;
-	g_cg.n_slices = J->n_slices;
-	g_cg.slices = (cg_slice_t *)calloc((size_t)J->n_slices, sizeof(cg_slice_t));
-	for (i = 0; i < J->n; ++i) ub += J->regs[i].n; /* no slice can ask for more entries than there are regions */
-	for (g_cg.cap = 64; g_cg.cap < 2 * ub; g_cg.cap <<= 1) {}
-	g_cg.tab = (cg_entry_t *)calloc(g_cg.cap, sizeof(cg_entry_t)); /* (untouched pages: the slices' threads fault them in) */
-	if (!g_cg.tab) bmh_tls_die("out of memory for the CIGAR table", BMH_E_NOMEM);
-	kt_for(n_threads, qa_cigar_slice, J, J->n_slices);
-	for (s = 0; s < J->n_slices; ++s) total += g_cg.slices[s].n_req;
-	if (getenv("BMH_VERBOSE")) fprintf(stderr, "[bwamem_hip] phase 2: %zu regions through bmh_reg2cigar_batch in %d slices\n", total, J->n_slices);
-}
-
-static void qa_cigar_cache_drop(void)
-{
-	int s;
-	if (getenv("BMH_VERBOSE") && g_cg.tab)
-		fprintf(stderr, "[bwamem_hip] phase 2: bwa_gen_cigar2 served %lld calls from the batch, %lld went to the host\n", g_cg.hits, g_cg.misses);
-	for (s = 0; s < g_cg.n_slices; ++s) free(g_cg.slices[s].reqs), free(g_cg.slices[s].res), free(g_cg.slices[s].cig), free(g_cg.slices[s].md);
-	free(g_cg.tab), free(g_cg.slices);
-	memset(&g_cg, 0, sizeof(g_cg));
 }
 
 /* mate rescue, one slice of pairs per host thread */
@@ -630,49 +459,60 @@ static void qa_matesw_slice(void *data, int k, int tid)
 	if (st.rounds > g_msw_rounds_max) g_msw_rounds_max = st.rounds; /* (a benign race: statistics only) */
 }
 
-static void qa_worker2_se(void *data, int i, int tid) /* == the SE branch of worker2, bwamem.c:1285-1289 */
+/* phase 2, one slice of reads (whole pairs) per host thread: worker2 of the reference (bwamem.c:1281-1295) */
+static long long g_sam_us[2]; /* thread-microseconds: waiting for a GPU place, bmh_sam_batch */
+static void qa_sam_slice(void *data, int k, int tid)
 {
-	qa_worker_t *w = (qa_worker_t *)data;
+	const qa_slice_job_t *J = (const qa_slice_job_t *)data;
+	const int unit = (J->sopt->flag & BMH_MEM_F_PE) ? 2 : 1, nu = J->n / unit;
+	const int lo = unit * (int)((int64_t)nu * k / J->n_slices), hi = unit * (int)((int64_t)nu * (k + 1) / J->n_slices);
+	bmh_ctx_t *ctx;
+	double t0, t1, t2;
+	int rc, i;
 	(void)tid;
-	mem_mark_primary_se(w->opt, (int)w->regs[i].n, w->regs[i].a, w->n_processed + i);
-	mem_reg2sam_se(w->opt, w->bns, w->pac, &w->seqs[i], &w->regs[i], 0, 0);
-	free(w->regs[i].a);
+	if (hi <= lo) return;
+	t0 = realtime();
+	gpu_enter();
+	t1 = realtime();
+	ctx = qa_slice_ctx(J);
+	if ((rc = bmh_sam_batch(ctx, J->sopt, (const bmh_refidx_t *)J->bns, J->pac, J->pes, J->n_processed + lo, hi - lo, (bmh_seq_t *)(J->seqs + lo),
+	                        J->regs + lo, bwa_rg_id)))
+		bmh_tls_die(rc == BMH_E_ARG ? "a region could not be turned into an alignment (the reference aborts here too, bwamem.c:1183-1186)" : bmh_last_error(ctx), rc);
+	bmh_pool_put(ctx);
+	gpu_leave();
+	t2 = realtime();
+	for (i = lo; i < hi; ++i) free(J->regs[i].a);
+	__sync_fetch_and_add(&g_sam_us[0], (long long)((t1 - t0) * 1e6)), __sync_fetch_and_add(&g_sam_us[1], (long long)((t2 - t1) * 1e6));
 }
-
-typedef void (*process_seqs_fn)(const ref_mem_opt_t *, const void *, const ref_bntseq_head_t *, const uint8_t *, int64_t, int,
-                                ref_bseq1_t *, const bmh_pestat_t *);
 
 void mem_process_seqs(const ref_mem_opt_t *opt, const void *bwt, const ref_bntseq_head_t *bns, const uint8_t *pac,
                       int64_t n_processed, int n, ref_bseq1_t *seqs, const bmh_pestat_t *pes0)
 {
-	const char *e = getenv("BMH_MATESW_BATCH"), *c = getenv("BMH_CIGAR_BATCH");
 	const int pe = (opt->flag & REF_MEM_F_PE) != 0;
-	const int rescue = pe && !(opt->flag & REF_MEM_F_NO_RESCUE) && !(e && e[0] == '0');
-	const int cigars = !(c && c[0] == '0');
+	const int rescue = pe && !(opt->flag & REF_MEM_F_NO_RESCUE);
 	qa_worker_t w;
 	bmh_pestat_t pes[4];
-	ref_mem_opt_t opt2;
 	bmh_params_t p;
+	bmh_sam_opt_t so;
 	bmh_read_t *reads;
 	qa_slice_job_t J;
-	double ctime, rtime, t_[5];
+	double ctime, rtime, t_[4];
 	int i;
-	if (!rescue && !cigars) { /* nothing to add: the reference's own function (its phase 1 still comes through the seam) */
-		static process_seqs_fn next;
-		if (!next) next = (process_seqs_fn)dlsym(RTLD_NEXT, "mem_process_seqs");
-		if (!next) bmh_tls_die("no other mem_process_seqs is loaded", BMH_E_ARG);
-		next(opt, bwt, bns, pac, n_processed, n, seqs, pes0);
-		return;
-	}
 	ctime = cputime(), rtime = realtime();
 	t_[0] = rtime;
-	w.opt = opt, w.bwt = bwt, w.bns = bns, w.pac = pac, w.seqs = seqs, w.n_processed = n_processed, w.pes = pes;
+	w.opt = opt, w.bwt = bwt, w.bns = bns, w.pac = pac, w.seqs = seqs;
 	w.regs = (bmh_alnreg_v *)malloc((size_t)n * sizeof(bmh_alnreg_v));
 	kt_for_batch(opt->n_threads, qa_worker1_batched, &w, n, opt->batch_size); /* bwamem.c:1313 */
 	t_[1] = realtime();
+	memset(&so, 0, sizeof(so)); /* the fields of mem_opt_t phase 2 reads */
+	so.a = opt->a, so.b = opt->b, so.o_del = opt->o_del, so.e_del = opt->e_del, so.o_ins = opt->o_ins, so.e_ins = opt->e_ins;
+	so.pen_unpaired = opt->pen_unpaired, so.w = opt->w, so.T = opt->T, so.flag = opt->flag, so.min_seed_len = opt->min_seed_len;
+	so.max_ins = opt->max_ins, so.mapQ_coef_fac = opt->mapQ_coef_fac, so.max_matesw = opt->max_matesw, so.mask_level = opt->mask_level;
+	so.mask_level_redun = opt->mask_level_redun, so.mapQ_coef_len = opt->mapQ_coef_len;
+	memcpy(so.mat, opt->mat, 25);
 	if (pe) {                                                                /* bwamem.c:1314-1317 */
 		if (pes0) memcpy(pes, pes0, 4 * sizeof(bmh_pestat_t));
-		else mem_pestat(opt, bns->l_pac, n, w.regs, pes);
+		else bmh_pestat(&so, bns->l_pac, n, w.regs, pes, bwa_verbose);
 	}
 	/* reads are base codes by now (bwamem.c:1093-1094) */
 	reads = (bmh_read_t *)malloc(sizeof(bmh_read_t) * (size_t)n);
@@ -686,9 +526,9 @@ void mem_process_seqs(const ref_mem_opt_t *opt, const void *bwt, const ref_bntse
 		J.resident = !(pr && pr[0] == '0');
 	}
 	J.opt = opt, J.bns = bns, J.pac = pac, J.n = n, J.seqs = seqs, J.regs = w.regs, J.reads = reads, J.params = &p, J.pes = pes;
+	J.sopt = &so, J.n_processed = n_processed;
 	J.n_slices = opt->n_threads > 0 ? opt->n_threads : 1;
-	opt2 = *opt;
-	if (rescue) { /* the whole chunk's mate rescue, one bmh_matesw_batch per host thread over its share of the pairs */
+	if (rescue) { /* the whole chunk's mate rescue (the block of mem_sam_pe at bwamem_pair.c:251-263), one bmh_matesw_batch per slice */
 		/* a slice holds its place on the GPU for all its rounds, and the rounds of a slice cost latency, not throughput:
 		 * more slices than places would only run one after the other (32 threads: 0.10 s against 0.04 s with 8 slices) */
 		const int all = J.n_slices;
@@ -699,29 +539,22 @@ void mem_process_seqs(const ref_mem_opt_t *opt, const void *bwt, const ref_bntse
 		if (getenv("BMH_VERBOSE"))
 			fprintf(stderr, "[bwamem_hip] mate rescue: %d pairs, %lld ksw_align2 calls in %lld GPU rounds, %lld pool bytes\n", n >> 1,
 			        g_msw_calls, g_msw_rounds_max, g_msw_bytes);
-		opt2.flag |= REF_MEM_F_NO_RESCUE; /* mem_sam_pe then skips bwamem_pair.c:251-263 */
 	}
 	t_[2] = realtime();
-	if (cigars) qa_cigar_cache_build(&J, opt->n_threads);
+	kt_for(opt->n_threads, qa_sam_slice, &J, J.n_slices); /* bwamem.c:1318-1319 */
 	t_[3] = realtime();
 	free(reads);
-	w.opt = &opt2;
-	if (pe) kt_for(opt->n_threads, qa_worker2_pe, &w, n >> 1); /* bwamem.c:1319 */
-	else kt_for(opt->n_threads, qa_worker2_se, &w, n);
-	t_[4] = realtime();
-	if (getenv("BMH_VERBOSE"))
+	if (getenv("BMH_VERBOSE")) {
 		fprintf(stderr, "[bwamem_hip] seeding batch thread-seconds so far: bmh_smem_batch %.3f, look-up keys %.3f, bmh_sa_batch %.3f\n",
 		        g_seed_us[0] * 1e-6, g_seed_us[1] * 1e-6, g_seed_us[2] * 1e-6);
-	if (getenv("BMH_VERBOSE"))
 		fprintf(stderr, "[bwamem_hip] phase 1 thread-seconds so far: wait %.3f, seeding batch %.3f, chaining on the host %.3f, wait %.3f, extension batch %.3f\n",
 		        g_p1_us[0] * 1e-6, g_p1_us[1] * 1e-6, g_p1_us[2] * 1e-6, g_p1_us[3] * 1e-6, g_p1_us[4] * 1e-6);
-	if (getenv("BMH_VERBOSE"))
 		fprintf(stderr, "[bwamem_hip] seeding: bwt_smem1 %lld from the batch / %lld on the host, bwt_sa %lld / %lld\n", g_seed_stats[0],
 		        g_seed_stats[1], g_seed_stats[2], g_seed_stats[3]);
-	if (getenv("BMH_VERBOSE"))
-		fprintf(stderr, "[bwamem_hip] chunk of %d reads: phase 1 %.3f s, pestat + mate rescue %.3f s, CIGAR batch %.3f s, phase 2 %.3f s\n", n,
-		        t_[1] - t_[0], t_[2] - t_[1], t_[3] - t_[2], t_[4] - t_[3]);
-	if (cigars) qa_cigar_cache_drop();
+		fprintf(stderr, "[bwamem_hip] phase 2 thread-seconds so far: wait %.3f, bmh_sam_batch %.3f\n", g_sam_us[0] * 1e-6, g_sam_us[1] * 1e-6);
+		fprintf(stderr, "[bwamem_hip] chunk of %d reads: phase 1 %.3f s, pestat + mate rescue %.3f s, phase 2 (marking, pairing, global alignments, SAM) %.3f s\n", n,
+		        t_[1] - t_[0], t_[2] - t_[1], t_[3] - t_[2]);
+	}
 	free(w.regs);
 	if (bwa_verbose >= 3)
 		fprintf(stderr, "[M::%s] Processed %d reads in %.3f CPU sec, %.3f real sec\n", __func__, n, cputime() - ctime, realtime() - rtime);

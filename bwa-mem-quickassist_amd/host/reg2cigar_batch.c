@@ -162,6 +162,7 @@ int bmh_reg2cigar_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, const
 		c->w2 = infer_bw(c->ql, c->tl, r->truesc, p->a, p->o_ins, p->e_ins);
 		c->w2 = c->w2 > tmp ? c->w2 : tmp;
 		if (c->w2 > p->w) c->w2 = c->w2 < r->reg_w ? c->w2 : r->reg_w;
+		if (r->truesc == INT32_MIN) c->w2 = r->reg_w; /* a single bwa_gen_cigar2(w_ = reg_w): bwa_fix_xref2's call, bwa.c:198 */
 		c->last_sc = -(1 << 30), c->active = 1;
 	}
 	memset(pool + pool_bytes, 0, 16);
@@ -236,7 +237,7 @@ int bmh_reg2cigar_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, const
 			if (c->score == c->last_sc) c->active = 0; /* bwamem.c:1198 */
 			else {
 				c->last_sc = c->score, c->w2 <<= 1;
-				if (!(c->tries < 3 && c->score < reqs[k].truesc - p->a)) c->active = 0; /* bwamem.c:1201 */
+				if (reqs[k].truesc == INT32_MIN || !(c->tries < 3 && c->score < reqs[k].truesc - p->a)) c->active = 0; /* bwamem.c:1201 */
 			}
 			n_active += c->active;
 		}

@@ -212,6 +212,9 @@ int bmh_last_extend_bin_ms(bmh_ctx_t *ctx, float ms[6]);
 /* Per-kernel duration of the last global-alignment launch: the 64-slot lane kernel (w <= 31), the 128-slot one (w <= 63),
  * the one-wave-per-task kernel (everything else).  -1 when timing was off. */
 int bmh_last_global_bin_ms(bmh_ctx_t *ctx, float ms[3]);
+/* Duration of the four rounds of the last fused per-seed launch (left, left at 2w, right, right at 2w), each with the
+ * small list-building kernel in front of it.  -1 when timing was off. */
+int bmh_last_seedext_round_ms(bmh_ctx_t *ctx, float ms[4]);
 
 /* ---- L3: data carriers of the extension driver, layout-compatible with the
  * reference so that its structs can be passed straight through. */
@@ -269,7 +272,8 @@ typedef struct bmh_cigar_req {
 	int32_t read;    /* index into reads[]                                              */
 	int32_t qb, qe;  /* query interval [qb,qe)                    (mem_alnreg_t.qb/qe)   */
 	int64_t rb, re;  /* reference interval, doubled coordinate    (mem_alnreg_t.rb/re)   */
-	int32_t truesc;  /* mem_alnreg_t.truesc: band inference + retry test, bwamem.c:1187,1201 */
+	int32_t truesc;  /* mem_alnreg_t.truesc: band inference + retry test, bwamem.c:1187,1201;
+	                    INT32_MIN = ONE bwa_gen_cigar2 call with w_ = reg_w instead of that loop (bwa_fix_xref2, bwa.c:198) */
 	int32_t reg_w;   /* mem_alnreg_t.w:      cap of the inferred band, bwamem.c:1191     */
 } bmh_cigar_req_t;
 
@@ -376,6 +380,63 @@ typedef int (*bmh_dedup_fn)(void *user, int n, bmh_alnreg_t *a);
 int bmh_matesw_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n_pairs, const bmh_read_t *reads,
                      bmh_alnreg_v *regs, const bmh_pestat_t pes[4], const bmh_matesw_opt_t *o, bmh_dedup_fn dedup,
                      void *dedup_user, int *n_sw);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Region post-processing and SAM text: everything mem_process_seqs does with a read's region
+ * vector after the extensions -- host code (plain C, batched per chunk slice), with the one DP it contains
+ * (ksw_global2 under mem_reg2aln / bwa_fix_xref2) run as GPU batches.
+ * Replaces: mem_sort_and_dedup (reference bwamem.c:395-436), mem_mark_primary_se (:445-475), mem_approx_mapq_se
+ *           (:1023-1047), mem_reg2aln (:1164-1236) over bwa_fix_xref2 (bwa.c:179-222), mem_aln2sam (:904-1017),
+ *           mem_reg2sam_se (:1049-1083); mem_pestat (bwamem_pair.c:46-107), mem_pair (:177-238), mem_sam_pe (:240-332)
+ *           -- i.e. worker2 of mem_process_seqs (bwamem.c:1281-1295).
+ * Ties in the reference's unstable sorts decide which duplicate survives and which hit is primary; the library sorts
+ * with the same comparison/exchange sequence (host/sort_exact.h), so the output order is the reference's. */
+typedef struct bmh_sam_opt { /* the mem_opt_t fields phase 2 reads (bwamem.h:21-48); scoring as in bmh_params_t */
+	int32_t a, b, o_del, e_del, o_ins, e_ins, pen_unpaired, w;
+	int32_t T, flag, min_seed_len, max_ins, mapQ_coef_fac, max_matesw;
+	float mask_level, mask_level_redun, mapQ_coef_len;
+	int8_t mat[25];
+	int8_t pad_[3];
+} bmh_sam_opt_t;
+#define BMH_MEM_F_PE 0x2        /* bwamem.h:14-20 */
+#define BMH_MEM_F_NOPAIRING 0x4
+#define BMH_MEM_F_ALL 0x8
+#define BMH_MEM_F_NO_MULTI 0x10
+#define BMH_MEM_F_NO_RESCUE 0x20
+
+typedef struct bmh_refann { /* == bntann1_t, bntseq.h:39-45: one reference sequence */
+	int64_t offset;
+	int32_t len, n_ambs;
+	uint32_t gi;
+	char *name, *anno;
+} bmh_refann_t;
+typedef struct bmh_refidx { /* == the head of bntseq_t, bntseq.h:53-61 (a bntseq_t* may be passed) */
+	int64_t l_pac;
+	int32_t n_seqs;
+	uint32_t seed;
+	bmh_refann_t *anns;
+} bmh_refidx_t;
+typedef struct bmh_seq { /* == bseq1_t, bwa.h:19-22; seq holds base codes (after bwamem.c:1093-1094); sam is malloc'd */
+	int32_t l_seq;
+	char *name, *comment, *seq, *qual, *sam;
+} bmh_seq_t;
+
+int bmh_sort_and_dedup(int n, bmh_alnreg_t *a, float mask_level_redun);                       /* mem_sort_and_dedup  */
+void bmh_mark_primary_se(const bmh_sam_opt_t *o, int n, bmh_alnreg_t *a, int64_t id);         /* mem_mark_primary_se */
+int bmh_approx_mapq_se(const bmh_sam_opt_t *o, const bmh_alnreg_t *a);                         /* mem_approx_mapq_se  */
+/* mem_pestat; with verbose >= 3 it prints the reference's "[M::mem_pestat] ..." lines to stderr */
+void bmh_pestat(const bmh_sam_opt_t *o, int64_t l_pac, int n, const bmh_alnreg_v *regs, bmh_pestat_t pes[4], int verbose);
+/* mem_pair (bwamem_pair.c:177-238): the best-scoring properly oriented pair of hits of the two ends; returns its score
+ * (0 = none), *sub / *n_sub the runner-up and how many lie within one event of it, z[] the chosen hit of each end */
+int bmh_pair(const bmh_sam_opt_t *o, int64_t l_pac, const bmh_pestat_t pes[4], const bmh_alnreg_v a[2], uint64_t id, int *sub,
+             int *n_sub, int z[2]);
+/* Phase 2 for reads [0,n) of a chunk slice: marks primaries, pairs (when o->flag has BMH_MEM_F_PE: n is even, reads 2p
+ * and 2p+1 are mates, pes = the four insert-size models, mate rescue already done or off), runs the global alignments
+ * of exactly the regions that get printed as GPU batches, and writes seqs[i].sam (malloc'd, the caller frees it as
+ * fastmap.c:201 does).  id0 = n_processed + index of read 0 (the reference's per-read id, bwamem.c:1287,1291).
+ * rg_id: the reference's bwa_rg_id ("" = none).  regs[i].a is left sorted/marked as the reference leaves it. */
+int bmh_sam_batch(bmh_ctx_t *ctx, const bmh_sam_opt_t *o, const bmh_refidx_t *bns, const uint8_t *pac, const bmh_pestat_t *pes,
+                  int64_t id0, int n, bmh_seq_t *seqs, bmh_alnreg_v *regs, const char *rg_id);
 
 /* ------------------------------------------------------------------------------------------------------------
  * FM-index queries of the seeding stage (first slice): super-maximal exact matches and suffix-

@@ -1,5 +1,5 @@
 """The driver's contract for bench.py: ONE JSON line with the agreed keys, the metric string of BASELINE.json, the roofline
-and cpu_baseline objects, bit-exact parity.  Run small here; the driver runs the default sizes."""
+and cpu_baseline objects, bit-exact parity.  Run small here; the driver runs the default sizes (10 M pairs per step)."""
 import json
 import os
 import subprocess
@@ -11,24 +11,22 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_bench_prints_one_contract_line():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
-                        "--reads", "60000", "--global-tasks", "20000", "--sw-tasks", "20000", "--seed-reads", "0",
-                        "--cpu-seconds", "1"], capture_output=True, timeout=600, cwd=ROOT)
+def _run(args):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
     assert len(lines) == 1
-    d = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def _contract(d, steps, warmup):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     if os.path.exists(os.path.join(ROOT, "BASELINE.json")):
         assert d["metric"] == json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
-    assert d["unit"] == "reads/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["unit"] == "reads/s" and d["n_gpus"] == 1 and d["steps"] == steps and d["warmup"] == warmup
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
-    # value = reads per second over exactly the timed steps (reads without any extension task -- ~2 % -- are not counted)
-    per_step = d["config"]["reads_per_gpu"] / (d["ms_per_step"] * 1e-3)
-    assert 0.9 * per_step < d["value"] <= per_step * (1 + 1e-9)
     assert "workload" in d["config"] and "model" not in d["config"]
     rf = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
@@ -39,4 +37,31 @@ def test_bench_prints_one_contract_line():
         assert k in cb, k
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0
     assert d["parity"].startswith("bit-exact")
+
+
+def test_bench_prints_one_contract_line_on_the_metric_config():
+    """configs[2] shape, whole DP path in the step (fused seed extension -> global -> rescue), scaled down."""
+    d = _run(["--gpus", "1", "--steps", "3", "--warmup", "1", "--pairs", "60000", "--chunk-reads", "40000", "--cpu-seconds", "1",
+              "--pipeline-reads", "20000", "--pipeline-genome", "500000"])
+    _contract(d, 3, 1)
+    assert "configs[2]" in d["config"]["workload"] and d["config"]["chunks"] == 3
+    # value = reads per second over exactly the timed steps; a pair counts as two reads
+    per_step = d["config"]["reads_per_gpu"] / (d["ms_per_step"] * 1e-3)
+    assert d["config"]["reads_per_gpu"] == 120000 and abs(d["value"] - per_step) <= 1e-6 * per_step
+    st = d["stages_ms_per_step"]
+    assert all(st[k] > 0 for k in ("seed_extension", "global_alignment", "mate_rescue_sw"))
+    ks = d["roofline"]["kernels"]
+    assert any("round R1" in k["kernel"] for k in ks) and any("global_lane_kernel<64>" in k["kernel"] for k in ks)
+    assert d["config"]["ksw_extend2_calls_per_gpu"] > d["config"]["seeded_reads_per_gpu"]  # left AND right flanks
+    pb = d["cpu_baseline_pipeline"]
+    if "skipped" not in pb:  # needs oracle/_ref (travels with the tree)
+        assert pb["kind"] == "reference" and pb["value"] > 0 and pb["dut_value"] > 0 and pb["sam_identical"] is True
+        assert pb["dut_detail"]["cigar_table"]["to_host"] == 0
+
+
+def test_bench_round1_line_still_runs():
+    d = _run(["--workload", "se1m", "--gpus", "1", "--steps", "3", "--warmup", "1", "--reads", "60000", "--global-tasks", "20000",
+              "--sw-tasks", "20000", "--seed-reads", "0", "--cpu-seconds", "1"])
+    _contract(d, 3, 1)
+    assert d["config"]["workload"].startswith("se1m")
     assert d["global_alignment"]["parity"].startswith("bit-exact") and d["mate_rescue_sw"]["parity"].startswith("bit-exact")
