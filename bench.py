@@ -137,16 +137,20 @@ def pipeline_baseline(n_reads, genome_bp, threads, batch=8192, noisy=0.3, dut=Tr
 
 
 def host_cores():
-    """(threads usable by this process, what limits them)"""
+    """(host cores this process can actually use, what limits them): the affinity mask cut to the cgroup's CPU quota --
+    on the 1-GPU boxes of this pool 256 hardware threads are visible but the container is entitled to 16 CPUs' worth,
+    and more runnable threads than that only get throttled"""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     note = f"{n} hardware threads in the affinity mask"
     try:
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()
         if q != "max":
-            note += f", cgroup cpu.max {q}/{per} = {int(q) / int(per):.1f} CPUs"
+            quota = int(q) / int(per)
+            note += f", cgroup cpu.max {q}/{per} = {quota:.1f} CPUs"
+            n = max(1, min(n, int(quota + 0.999)))
     except Exception:
         pass
-    return n, note
+    return n, note + f" -> {n} threads used"
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -161,6 +165,7 @@ def main():
     ap.add_argument("--chunk-reads", type=int, default=1_000_000, help="reads per streamed chunk")
     ap.add_argument("--global-per-read", type=float, default=0.85, help="ksw_global2 tasks per read (measured, SURVEY.md §8a2)")
     ap.add_argument("--rescue-rate", type=float, default=0.06, help="ksw_align2 mate-rescue tasks per pair (measured 0.02-0.11)")
+    ap.add_argument("--rescue-batch", type=int, default=1_000_000, help="mate-rescue tasks are collected over chunks into batches of up to this many")
     ap.add_argument("--streams", type=int, default=1, help="1: the three stages of a chunk back to back on one stream; 3: one context and stream per stage")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the oracle-port CPU baseline (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -221,29 +226,37 @@ def main():
         nr = sizes[k]
         pool, seeds = tg.generate_seeds(params, nr, args.shape, seed=s0)
         gpool, gtasks, gwords = tg.generate_global(max(1, int(round(nr * args.global_per_read))), args.shape, seed=s0 + 5)
-        spool, stasks = tg.generate_sw(params, max(1, int(round(nr / 2 * args.rescue_rate))), args.shape, seed=s0 + 9)
-        return pool, seeds, gpool, gtasks, gwords, spool, stasks
+        return pool, seeds, gpool, gtasks, gwords
+
+    n_sw_step = max(1, int(round(args.pairs * args.rescue_rate)))
+    n_swb = max(1, (n_sw_step + args.rescue_batch - 1) // args.rescue_batch)
+    sw_sizes = [n_sw_step * (k + 1) // n_swb - n_sw_step * k // n_swb for k in range(n_swb)]
+
+    def gen_sw(k):
+        return tg.generate_sw(params, sw_sizes[k], args.shape, seed=sh.shard_seed(7, rank) * 131 + 9 + 1000 * k)
 
     workers = max(1, min(16, ncores, n_chunks))
     note(f"generating {n_reads_step} reads' worth of tasks in {n_chunks} chunks on {workers} threads")
     with ThreadPoolExecutor(max_workers=workers) as ex:
         host = list(ex.map(gen, range(n_chunks)))
+        host_sw = list(ex.map(gen_sw, range(n_swb)))
     gen_s = time.time() - t0
 
     note(f"generated in {gen_s:.1f} s; uploading")
     t0 = time.time()
     chunks = []
     up = lambda a: torch.from_numpy(a.view(np.uint8).reshape(-1)).to(dev)
-    for pool, seeds, gpool, gtasks, gwords, spool, stasks in host:
+    for pool, seeds, gpool, gtasks, gwords in host:
         chunks.append({"pool": up(pool), "seeds": up(seeds), "n": len(seeds), "gpool": up(gpool), "gtasks": up(gtasks), "ng": len(gtasks),
-                       "gwords": gwords, "spool": up(spool), "stasks": up(stasks), "ns": len(stasks),
+                       "gwords": gwords,
                        "sres": torch.zeros(len(seeds) * pkg.SEED_RES.itemsize, dtype=torch.uint8, device=dev),
-                       "gres": torch.zeros(len(gtasks) * pkg.GLB_RES.itemsize, dtype=torch.uint8, device=dev),
-                       "swres": torch.zeros(len(stasks) * pkg.SW_RES.itemsize, dtype=torch.uint8, device=dev)})
+                       "gres": torch.zeros(len(gtasks) * pkg.GLB_RES.itemsize, dtype=torch.uint8, device=dev)})
+    swb = [{"spool": up(spool), "stasks": up(stasks), "ns": len(stasks),
+            "swres": torch.zeros(len(stasks) * pkg.SW_RES.itemsize, dtype=torch.uint8, device=dev)} for spool, stasks in host_sw]
     d_cig = torch.zeros(max(c["gwords"] for c in chunks) + 8, dtype=torch.int32, device=dev)  # one chunk's CIGARs at a time
     upload_s = time.time() - t0
     n_seeded = sum(c["n"] for c in chunks)
-    n_glb, n_sw = sum(c["ng"] for c in chunks), sum(c["ns"] for c in chunks)
+    n_glb, n_sw = sum(c["ng"] for c in chunks), sum(b["ns"] for b in swb)
     qmax = int(max(max(int(h[1]["qbeg"].max()), int((h[1]["l_query"] - h[1]["qbeg"] - h[1]["len"]).max())) for h in host))
     gqmax = int(max(int(h[3]["qlen"].max()) for h in host))
 
@@ -260,11 +273,15 @@ def main():
     def run_chunk(c, cig):
         cx_ext.seedext_batch_device(c["pool"].data_ptr(), c["seeds"].data_ptr(), c["n"], c["sres"].data_ptr())
         cx_glb.global_batch_device(c["gpool"].data_ptr(), c["gtasks"].data_ptr(), c["ng"], c["gres"].data_ptr(), cig.data_ptr())
-        cx_sw.sw_batch_device(c["spool"].data_ptr(), c["stasks"].data_ptr(), c["ns"], c["swres"].data_ptr())
+
+    def run_sw(b):
+        cx_sw.sw_batch_device(b["spool"].data_ptr(), b["stasks"].data_ptr(), b["ns"], b["swres"].data_ptr())
 
     def step():
         for c in chunks:
             run_chunk(c, d_cig)
+        for b in swb:  # the step's mate rescue: the pairs of all chunks, in batches large enough to fill the chip
+            run_sw(b)
 
     def sync_all():
         for s in streams:
@@ -309,12 +326,10 @@ def main():
         c.set_kernel_timing(True)
     evs = []
     for c in chunks:
-        e = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
         e[0].record(streams[0]); cx_ext.seedext_batch_device(c["pool"].data_ptr(), c["seeds"].data_ptr(), c["n"], c["sres"].data_ptr()); e[1].record(streams[0])
         sg = streams[1 % len(streams)]
         e[2].record(sg); cx_glb.global_batch_device(c["gpool"].data_ptr(), c["gtasks"].data_ptr(), c["ng"], c["gres"].data_ptr(), d_cig.data_ptr()); e[3].record(sg)
-        ss = streams[2 % len(streams)]
-        e[4].record(ss); cx_sw.sw_batch_device(c["spool"].data_ptr(), c["stasks"].data_ptr(), c["ns"], c["swres"].data_ptr()); e[5].record(ss)
         sync_all()
         round_ms += np.array(cx_ext.last_seedext_round_ms())
         gbin_ms += np.maximum(np.array(cx_glb.last_global_bin_ms()), 0.0)
@@ -322,7 +337,12 @@ def main():
     for e in evs:
         stage_ms["seed_extension"] += e[0].elapsed_time(e[1])
         stage_ms["global_alignment"] += e[2].elapsed_time(e[3])
-        stage_ms["mate_rescue_sw"] += e[4].elapsed_time(e[5])
+    ss = streams[2 % len(streams)]
+    for b in swb:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(ss); run_sw(b); e1.record(ss)
+        sync_all()
+        stage_ms["mate_rescue_sw"] += e0.elapsed_time(e1)
     for c in ctxs:
         c.set_kernel_timing(False)
 
@@ -331,14 +351,15 @@ def main():
         note("parity check and CPU baseline")
         # ---- parity on chunk 0 (its results are still on the device; CIGARs: run its global batch once more) + CPU baseline
         c0, h0 = chunks[0], host[0]
-        pool, seeds, gpool, gtasks, gwords, spool, stasks = h0
+        pool, seeds, gpool, gtasks, gwords = h0
+        spool, stasks = host_sw[0]
         cig0 = torch.zeros(gwords + 8, dtype=torch.int32, device=dev)
         cx_glb.global_batch_device(c0["gpool"].data_ptr(), c0["gtasks"].data_ptr(), c0["ng"], c0["gres"].data_ptr(), cig0.data_ptr())
         sync_all()
         sres = c0["sres"].cpu().numpy().view(pkg.SEED_RES)
         gres = c0["gres"].cpu().numpy().view(pkg.GLB_RES)
         gcig = cig0.cpu().numpy().view(np.uint32)
-        swres = c0["swres"].cpu().numpy().view(pkg.SW_RES)
+        swres = swb[0]["swres"].cpu().numpy().view(pkg.SW_RES)
         ns = min(len(seeds), 20000)
         want, cells, calls = kswlib.orc_seedext_batch(params, pool, seeds[:ns], nthreads=ncores)
         ok_ext = all(bool((want[f] == sres[:ns][f]).all()) for f in want.dtype.names)
@@ -367,7 +388,7 @@ def main():
             K = int(min(sizes[0], max(20000, args.cpu_seconds / max(per_read, 1e-9) * 0.7)))
             ke = min(len(seeds), int(K * len(seeds) / sizes[0]))
             kg = min(len(gtasks), int(K * len(gtasks) / sizes[0]))
-            kw = max(1, min(len(stasks), int(K * len(stasks) / sizes[0])))
+            kw = max(1, min(len(stasks), int(K * n_sw / n_reads_step)))
             t1 = time.perf_counter()
             w1, cells1, calls1 = kswlib.orc_seedext_batch(params, pool, seeds[:ke], nthreads=ncores)
             t_e = time.perf_counter() - t1
@@ -400,7 +421,7 @@ def main():
         seeds_all_q = np.concatenate([h[1]["l_query"].astype(np.int64) for h in host])
         seeds_all_w = np.concatenate([h[1]["wlen"].astype(np.int64) for h in host])
         ext_bytes = float((seeds_all_q + seeds_all_w).sum() + n_seeded * (40 + 32))  # read + window + the 40 B record + 32 B result
-        sw_bytes = float(sum((h[6]["qlen"].astype(np.int64) + h[6]["tlen"].astype(np.int64)).sum() + 64 * len(h[6]) for h in host))
+        sw_bytes = float(sum((t["qlen"].astype(np.int64) + t["tlen"].astype(np.int64)).sum() + 64 * len(t) for _, t in host_sw))
         kernels = []
         names = ["round L1: left extensions (extend_lane_kernel<32|64|128> + seed_left_make)", "round L2: left retries at 2w",
                  "round R1: right extensions, h0 = the device's left score", "round R2: right retries at 2w"]
@@ -412,7 +433,7 @@ def main():
         for b in range(3):
             kernels.append({"kernel": gnames[b], "ms": float(gbin_ms[b]), "launches": n_chunks, "tasks": int((gbin == b).sum()),
                             "algorithmic_bytes": float(g_bytes[gbin == b].sum())})
-        kernels.append({"kernel": "sw_lane_kernel<80> + second pass (ksw_align2, mate rescue)", "ms": stage_ms["mate_rescue_sw"], "launches": n_chunks,
+        kernels.append({"kernel": "sw_lane_kernel<80> + second pass (ksw_align2, mate rescue)", "ms": stage_ms["mate_rescue_sw"], "launches": n_swb,
                         "tasks": n_sw, "algorithmic_bytes": sw_bytes})
         for k in kernels:
             k["avg_launch_ms"] = k["ms"] / k["launches"]
@@ -444,7 +465,7 @@ def main():
                                    f"inputs resident in HBM; seeding, chaining and SAM text are host stages outside the step (see cpu_baseline_pipeline)",
                        "pairs_per_gpu": args.pairs, "reads_per_gpu": n_reads_step, "chunks": n_chunks, "seeded_reads_per_gpu": n_seeded,
                        "ksw_extend2_calls_per_gpu": int(round(calls_per_seed * n_seeded)), "global_tasks_per_gpu": n_glb, "rescue_tasks_per_gpu": n_sw,
-                       "mean_global_w": float(gw.mean()), "streams": args.streams,
+                       "rescue_batches": n_swb, "mean_global_w": float(gw.mean()), "streams": args.streams,
                        "parallelism": f"static shard x{world}, one process per GPU, no collective on the data path"},
             "tasks_per_s": tasks_all * args.steps / elapsed,
             "per_rank_ms_per_step": per_rank_ms,

@@ -89,7 +89,7 @@ class _Read(C.Structure):
 
 
 class _DriverStats(C.Structure):
-    _fields_ = [(n, C.c_int64) for n in ("rounds", "ext_tasks", "seeds_extended", "seeds_skipped", "pool_bytes", "seeds_speculated")]
+    _fields_ = [(n, C.c_int64) for n in ("rounds", "ext_tasks", "seeds_extended", "seeds_skipped", "pool_bytes", "seeds_speculated", "short_sw")]
 
 
 _lib = None

@@ -228,7 +228,10 @@ __global__ __launch_bounds__(256) void glb_sort_hist_kernel(const bmh_glb_task_t
 		const int worst = P.o_del + P.o_ins + emax * (qlen + tlen) + smax * max(qlen, tlen); // |score| bound of any cell
 		int bin = 2;
 		if (lane_ok && tlen <= rows_cap && worst < 12000 && w >= 0) bin = w <= 31 ? 0 : (w <= 63 ? 1 : 2);
-		const int bk = bin * kSortKeysHost + (bin < 2 ? min(tlen >> 1, kSortKeysHost - 1) : 0);
+		// inside a lane bin: rows first (lanes of a wave run until their longest target ends), then band width (a wave
+		// computes and stores the 8-slot blocks that ANY of its lanes needs, and its lanes' tracebacks share cache lines
+		// when they sit in the same block)
+		const int bk = bin * kSortKeysHost + (bin < 2 ? (min(tlen >> 3, 127) << 4 | (min(w, 63) >> (bin + 1) & 15)) : 0);
 		binkey[k] = (uint16_t)bk;
 		atomicAdd(&lh[bk], 1u);
 	}

@@ -15,9 +15,14 @@
 // "-inf" is -16384: every comparison of the reference that involves MINUS_INF (ksw.c:487) has a finite value on the
 // other side (a cell inside the band always has an in-band diagonal predecessor), so any sentinel below all finite
 // scores reproduces it; the dispatcher sends tasks whose scores could reach -12000 to the int32 wave kernel.
-// Direction bytes (same encoding as ksw.c:547-561) are packed four per dword and written to a per-wave HBM slab
-// laid out [row][slot/4][lane], so both the stores of the fill and the loads of the per-lane traceback coalesce.
-// The traceback (ksw.c:566-581) is the reference's loop, one path per lane, CIGAR words written by the lane itself.
+// Direction state: the reference keeps one byte per cell (ksw.c:547-561: 2 bits "where H came from", 2 bits "E continues",
+// 2 bits "F continues", of which 4 bits carry information).  Here a cell costs 4 bits -- d | e_continues<<2 |
+// f_continues<<3 -- eight cells (one 8-slot block) per dword, and ONLY the blocks a wave computes are written, to a
+// per-wave HBM slab laid out [block][row][lane]: the fill's stores are one coalesced 256-byte line per block and row,
+// and the traceback (ksw.c:566-581: the reference's loop, one path per lane) walks up a block's rows, so the lanes of a
+// wave -- sorted by band width, hence with their paths in the same block -- share the lines they fetch.
+// (Round 1 stored a byte per cell for all C slots in [row][slot/4][lane] order: 3.35 GB of HBM traffic per 190 k tasks,
+// profiles/traffic_latest.json; most of it the traceback pulling a 64-byte sector per 4-byte read.)
 #include <algorithm>
 
 #include "bmh_ctx.h"
@@ -52,7 +57,7 @@ __global__ __launch_bounds__(64, (C <= 64 ? BMH_GL_WAVES64 : BMH_GL_WAVES128)) v
 		srow[lane] = make_uint2(lo, (uint32_t)(uint8_t)mat_at(P, lane * 5 + 4));
 	}
 	const long long cnt = count ? (long long)*count : n;
-	uint32_t *__restrict__ zw = zslab + (size_t)blockIdx.x * (size_t)rows_cap * (size_t)(NQ * 64) + lane;
+	uint32_t *__restrict__ zw = zslab + (size_t)blockIdx.x * (size_t)rows_cap * (size_t)(NB * 64) + lane;
 
 	for (long long base = (long long)blockIdx.x * 64; base < cnt; base += (long long)gridDim.x * 64) {
 		const bool valid = base + lane < cnt;
@@ -120,7 +125,7 @@ __global__ __launch_bounds__(64, (C <= 64 ? BMH_GL_WAVES64 : BMH_GL_WAVES128)) v
 			}
 			const int fill = i < w ? -(P.o_del + e_del * (i + 1)) : kNeg16; // ksw.c:530: first-column value while beg == 0
 			int f = kNeg16;
-			uint32_t *zrow = zw + (size_t)i * (size_t)(NQ * 64);
+			uint32_t *zrow = zw + (size_t)i * 64;
 #pragma unroll
 			for (int b = 0; b < NB; ++b) {
 				// needed iff the block meets [slo-1, shi): slot slo-1 is the virtual column -1 that must receive `fill`
@@ -139,19 +144,16 @@ __global__ __launch_bounds__(64, (C <= 64 ? BMH_GL_WAVES64 : BMH_GL_WAVES128)) v
 					d = h >= f ? d : 2;
 					h = max(h, f);
 					const int t1 = m - oe_del, e2 = e - e_del;         // ksw.c:552-556
-					d |= e2 > t1 ? 1 << 2 : 0;
+					d |= e2 > t1 ? 4 : 0;
 					const int en = max(e2, t1);
 					const int t2 = m - oe_ins, f2 = f - e_ins;         // ksw.c:557-560
-					d |= f2 > t2 ? 2 << 4 : 0;
+					d |= f2 > t2 ? 8 : 0;
 					f = sel3(actv, max(f2, t2), kNeg16);
 					// register s <- {H(i,j) for the next row's diagonal, E(i+1,j) for the next row's slot s-1}
 					R[s] = (int)__builtin_amdgcn_perm((unsigned)sel3(actv, en, kNeg16), (unsigned)sel3(actv, h, fill), 0x05040100u);
-					dz |= (uint32_t)d << (8 * (c & 3));
-					if ((c & 3) == 3) {
-						if (want) zrow[(size_t)(s / 4) * 64] = dz; // ksw.c:561
-						dz = 0;
-					}
+					dz |= (uint32_t)d << (4 * c);
 				}
+				if (want) zrow[(size_t)b * (size_t)rows_cap * 64] = dz; // ksw.c:561, eight cells at once
 			}
 			// score = eh[qlen].h after the LAST row of a lane = H(tlen-1, qlen-1), ksw.c:565: slot qlen-tlen+w of that row.
 			// Picked up right here because the registers of a finished lane are refilled by the rows other lanes still run.
@@ -180,8 +182,8 @@ __global__ __launch_bounds__(64, (C <= 64 ? BMH_GL_WAVES64 : BMH_GL_WAVES128)) v
 			while (__builtin_amdgcn_ballot_w64(on && ti >= 0 && tk >= 0)) {
 				if (on && ti >= 0 && tk >= 0) {
 					const int s = min(max(tk - (ti - w), 0), C - 1);
-					const uint32_t dzw = zw[((size_t)ti * NQ + (size_t)(s >> 2)) * 64];
-					which = (int)(dzw >> (8 * (s & 3)) >> (which << 1)) & 3;
+					const uint32_t nib = zw[((size_t)(s >> 3) * (size_t)rows_cap + (size_t)ti) * 64] >> (4 * (s & 7));
+					which = which == 0 ? (int)(nib & 3) : which == 1 ? (int)(nib >> 2 & 1) : (int)(nib >> 2 & 2);
 					const int op = which == 0 ? 0 : (which == 1 ? 2 : 1);
 					if (last_len > 0 && op == last_op) ++last_len; // ksw.c:489-499
 					else {
@@ -241,7 +243,7 @@ int launch_global_lane(bmh_ctx *ctx, int c, const uint8_t *d_pool, const bmh_glb
 	// (and for the waves this launch can actually have in flight: a context that only ever sees small batches must not
 	// pin gigabytes)
 	const size_t slab_waves = (size_t)std::min<long long>((n + 63) / 64, (long long)ncu * 4 * 2 * 2);
-	const size_t slab = slab_waves * (size_t)rows_cap * (size_t)(128 / 4) * 64 * 4;
+	const size_t slab = slab_waves * (size_t)rows_cap * (size_t)(128 / 8) * 64 * 4; // [block][row][lane] dwords, 8 cells each
 	int rc = ensure(ctx, ctx->d_zslab, slab);
 	if (rc) return rc;
 #define BMH_LAUNCH_GL(CC)                                                                                             \

@@ -81,7 +81,15 @@ typedef struct {
 	int64_t rmax0, rmax1;
 	uint64_t win_off; /* pool offset of the window's first base */
 	size_t seed_base; /* index of the chain's seed 0 in the flat result cache */
+	/* mem_chain2aln_short (bwamem.c:495-542), when the driver runs it itself: -1 = it returns without a Smith-Waterman
+	 * (the chain goes on to mem_chain2aln), else the index of its ksw_align2 in the batch's short-chain tasks */
+	int32_t sw_idx, sqb, sqe, seedcov;
+	int64_t srb, sre;
+	uint64_t swin_off; /* pool offset of [srb,sre) when the reference is not resident */
 } chain_win_t;
+
+#define MEM_SHORT_EXT 50  /* bwamem.c:491-492 */
+#define MEM_SHORT_LEN 200
 
 enum { ST_NEXT_CHAIN, ST_NEXT_SEED, ST_DONE };
 
@@ -176,7 +184,41 @@ typedef struct {
 	/* extension results by (chain, seed): 0 = not asked for, 1 = asked for in the round being built, 2 = there */
 	uint8_t *have;
 	bmh_seed_result_t *cache;
+	int short_msl; /* > 0: mem_chain2aln_short is the driver's own pre-step, with this opt->min_seed_len */
+	const bmh_sw_result_t *sw_res;
 } drv_t;
+
+/* The part of mem_chain2aln_short before its ksw_align2 (bwamem.c:504-527): does the chain qualify, and for which
+ * query / reference intervals?  Returns 1 and fills cw->s* if a Smith-Waterman is to be run. */
+static int short_candidate(const bmh_params_t *p, int64_t l_pac, int l_query, const bmh_chain_t *c, chain_win_t *cw)
+{
+	int i, qb = l_query, qe = 0, cov = 0;
+	int64_t rb = l_pac << 1, re = 0;
+	cw->sw_idx = -1;
+	if (c->n <= 0) return 0;
+	for (i = 0; i < c->n; ++i) {
+		const bmh_seed_t *s = &c->seeds[i];
+		qb = qb < s->qbeg ? qb : s->qbeg;
+		qe = qe > s->qbeg + s->len ? qe : s->qbeg + s->len;
+		rb = rb < s->rbeg ? rb : s->rbeg;
+		re = re > s->rbeg + s->len ? re : s->rbeg + s->len;
+		cov += s->len;
+	}
+	qb -= MEM_SHORT_EXT, qe += MEM_SHORT_EXT;
+	if (qb <= 10 || qe >= l_query - 10) return 0; /* ksw_align2 cannot align to the ends */
+	rb -= MEM_SHORT_EXT, re += MEM_SHORT_EXT;
+	rb = rb > 0 ? rb : 0;
+	re = re < l_pac << 1 ? re : l_pac << 1;
+	if (rb < l_pac && l_pac < re) {
+		if (c->seeds[0].rbeg < l_pac) re = l_pac;
+		else rb = l_pac;
+	}
+	if ((re - rb) - (qe - qb) > MEM_SHORT_EXT || (qe - qb) - (re - rb) > MEM_SHORT_EXT) return 0;
+	if (qe - qb >= p->w * 4 || re - rb >= p->w * 4) return 0;
+	if (qe - qb >= MEM_SHORT_LEN || re - rb >= MEM_SHORT_LEN) return 0;
+	cw->sqb = qb, cw->sqe = qe, cw->srb = rb, cw->sre = re, cw->seedcov = cov;
+	return 1;
+}
 
 /* Runs read r with the reference's control flow (bwamem.c:1101-1107 over :760-876) for as long as the extension results
  * it needs are cached.  Returns 0 when the read is finished, 1 when it stopped at a seed whose result is missing. */
@@ -194,6 +236,20 @@ static int run_read(drv_t *d, int r, rstate_t *rs)
 			c = &d->chains[r].a[rs->ci];
 			/* the caller's pre-step, e.g. mem_chain2aln_short (bwamem.c:1104/1140): <=0 means "chain done" */
 			if (d->pre && d->pre(d->pre_ud, r, rs->ci, &d->regs[r]) <= 0) continue;
+			if (d->short_msl > 0) { /* ... or the driver's own: the second half of mem_chain2aln_short, bwamem.c:533-541 */
+				const chain_win_t *cw = &d->wins[rs->chain_base + (size_t)rs->ci];
+				if (cw->sw_idx >= 0) {
+					const bmh_sw_result_t *x = &d->sw_res[cw->sw_idx];
+					if (!(x->tb < MEM_SHORT_EXT >> 1 || x->te > cw->sre - cw->srb - (MEM_SHORT_EXT >> 1))) {
+						bmh_alnreg_t *a = regs_push(&d->regs[r]);
+						memset(a, 0, sizeof(*a));
+						a->rb = cw->srb + x->tb, a->re = cw->srb + x->te + 1;
+						a->qb = cw->sqb + x->qb, a->qe = cw->sqb + x->qe + 1;
+						a->score = x->score, a->csub = x->score2, a->seedcov = cw->seedcov;
+						continue; /* the chain is settled */
+					}
+				}
+			}
 			if (c->n == 0) continue; /* bwamem.c:738 */
 			rs->srt = (uint64_t *)malloc((size_t)c->n * 8); /* bwamem.c:760-763 */
 			for (i = 0; i < c->n; ++i) rs->srt[i] = (uint64_t)c->seeds[i].len << 32 | (uint32_t)i;
@@ -277,8 +333,24 @@ static double now_s(void)
 	return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
+static int chains2regs(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n_reads, const bmh_read_t *reads,
+                       const bmh_chain_v *chains, bmh_chain_pre_fn pre, void *pre_ud, int short_msl, bmh_alnreg_v *regs);
+
 int bmh_chain2aln_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n_reads, const bmh_read_t *reads,
                         const bmh_chain_v *chains, bmh_chain_pre_fn pre, void *pre_ud, bmh_alnreg_v *regs)
+{
+	return chains2regs(ctx, l_pac, pac, n_reads, reads, chains, pre, pre_ud, 0, regs);
+}
+
+int bmh_chains2regs_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n_reads, const bmh_read_t *reads,
+                          const bmh_chain_v *chains, int min_seed_len, bmh_alnreg_v *regs)
+{
+	if (min_seed_len < 1) return BMH_E_ARG;
+	return chains2regs(ctx, l_pac, pac, n_reads, reads, chains, 0, 0, min_seed_len, regs);
+}
+
+static int chains2regs(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n_reads, const bmh_read_t *reads,
+                       const bmh_chain_v *chains, bmh_chain_pre_fn pre, void *pre_ud, int short_msl, bmh_alnreg_v *regs)
 {
 	const int trace = getenv("BMH_DRIVER_TRACE") != 0; /* where a call's time goes, on stderr */
 	double t_trace[4] = {0, 0, 0, 0};
@@ -287,9 +359,11 @@ int bmh_chain2aln_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n
 	chain_win_t *wins = 0;
 	uint8_t *pool = 0;
 	bmh_seed_result_t *res = 0;
+	bmh_sw_task_t *sw_tasks = 0;
+	bmh_sw_result_t *sw_res = 0;
 	int *stopped = 0;
 	req_t q;
-	size_t n_chains = 0, n_seeds = 0, pool_bytes = 0, ci_flat;
+	size_t n_chains = 0, n_seeds = 0, pool_bytes = 0, ci_flat, n_short = 0;
 	int r, rc = BMH_OK, n_stopped;
 
 	if (!ctx || n_reads < 0 || (n_reads > 0 && (!reads || !chains || !regs || !pac))) return BMH_E_ARG;
@@ -298,7 +372,7 @@ int bmh_chain2aln_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n
 	d.p = bmh_ctx_params_(ctx);
 	if (!d.p) return BMH_E_ARG;
 	if (n_reads == 0) return BMH_OK;
-	d.reads = reads, d.chains = chains, d.pre = pre, d.pre_ud = pre_ud, d.regs = regs;
+	d.reads = reads, d.chains = chains, d.pre = pre, d.pre_ud = pre_ud, d.regs = regs, d.short_msl = short_msl;
 	t_trace[0] = trace ? now_s() : 0;
 
 	/* pass 1: window of every live chain (bwamem.c:740-755) and pool layout */
@@ -316,8 +390,9 @@ int bmh_chain2aln_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n
 			chain_win_t *cw = &wins[ci_flat];
 			const int l_query = reads[r].l_seq;
 			int i;
-			cw->seed_base = n_seeds;
+			cw->seed_base = n_seeds, cw->sw_idx = -1;
 			if (c->n <= 0) continue;
+			if (short_msl > 0 && short_candidate(d.p, l_pac, l_query, c, cw)) cw->sw_idx = (int32_t)n_short++;
 			n_seeds += (size_t)c->n;
 			cw->rmax0 = l_pac << 1, cw->rmax1 = 0;
 			for (i = 0; i < c->n; ++i) {
@@ -343,6 +418,7 @@ int bmh_chain2aln_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n
 	for (ci_flat = 0; ci_flat < n_chains && !d.tpac; ++ci_flat) {
 		wins[ci_flat].win_off = pool_bytes;
 		pool_bytes += (size_t)(wins[ci_flat].rmax1 - wins[ci_flat].rmax0);
+		if (wins[ci_flat].sw_idx >= 0) wins[ci_flat].swin_off = pool_bytes, pool_bytes += (size_t)(wins[ci_flat].sre - wins[ci_flat].srb);
 	}
 	d.wins = wins;
 
@@ -352,12 +428,35 @@ int bmh_chain2aln_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n
 	d.cache = (bmh_seed_result_t *)malloc(sizeof(bmh_seed_result_t) * (n_seeds + 1));
 	if (!pool || !d.have || !d.cache) { rc = BMH_E_NOMEM; goto done; }
 	for (r = 0; r < n_reads; ++r) memcpy(pool + rs[r].read_off, reads[r].seq, (size_t)reads[r].l_seq);
-	for (ci_flat = 0; ci_flat < n_chains && !d.tpac; ++ci_flat)
+	for (ci_flat = 0; ci_flat < n_chains && !d.tpac; ++ci_flat) {
 		if (wins[ci_flat].rmax1 > wins[ci_flat].rmax0)
 			fetch_window(l_pac, pac, wins[ci_flat].rmax0, wins[ci_flat].rmax1, pool + wins[ci_flat].win_off);
+		if (wins[ci_flat].sw_idx >= 0) fetch_window(l_pac, pac, wins[ci_flat].srb, wins[ci_flat].sre, pool + wins[ci_flat].swin_off);
+	}
 	memset(pool + pool_bytes, 0, 16);
 	d.st.pool_bytes = (int64_t)pool_bytes + 16;
 	if ((rc = bmh_upload_pool(ctx, pool, pool_bytes + 16))) goto done;
+	if (n_short) { /* every ksw_align2 of the batch's mem_chain2aln_short calls (bwamem.c:529-531) as one GPU batch */
+		sw_tasks = (bmh_sw_task_t *)calloc(n_short, sizeof(bmh_sw_task_t));
+		sw_res = (bmh_sw_result_t *)malloc(sizeof(bmh_sw_result_t) * n_short);
+		if (!sw_tasks || !sw_res) { rc = BMH_E_NOMEM; goto done; }
+		for (r = 0, ci_flat = 0; r < n_reads; ++r) {
+			size_t ci;
+			for (ci = 0; ci < chains[r].n; ++ci, ++ci_flat) {
+				const chain_win_t *cw = &wins[ci_flat];
+				bmh_sw_task_t *t;
+				if (cw->sw_idx < 0) continue;
+				t = &sw_tasks[cw->sw_idx];
+				t->q_off = rs[r].read_off + (uint64_t)cw->sqb, t->qlen = (uint16_t)(cw->sqe - cw->sqb);
+				t->t_off = d.tpac ? (uint64_t)cw->srb : cw->swin_off, t->tlen = (uint32_t)(cw->sre - cw->srb);
+				t->flags = d.tpac ? BMH_F_TPAC : 0;
+				t->xtra = BMH_SW_XSUBO | BMH_SW_XSTART | ((cw->sqe - cw->sqb) * d.p->a < 250 ? BMH_SW_XBYTE : 0) | (uint32_t)(short_msl * d.p->a);
+			}
+		}
+		if ((rc = bmh_sw_batch(ctx, 0, 0, sw_tasks, (int64_t)n_short, sw_res))) goto done;
+		d.sw_res = sw_res;
+		d.st.short_sw = (int64_t)n_short;
+	}
 	t_trace[1] = trace ? now_s() : 0;
 
 	/* round 1: the seed each chain is extended from first -- the last one in (len, index) order, bwamem.c:760-765 */
@@ -430,6 +529,6 @@ int bmh_chain2aln_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n
 done:
 	if (rs) for (r = 0; r < n_reads; ++r) free(rs[r].srt);
 	bmh_ctx_set_driver_stats_(ctx, &d.st);
-	free(rs), free(wins), free(pool), free(res), free(stopped), free(q.t), free(q.slot), free(d.have), free(d.cache);
+	free(rs), free(wins), free(pool), free(res), free(stopped), free(q.t), free(q.slot), free(d.have), free(d.cache), free(sw_tasks), free(sw_res);
 	return rc;
 }

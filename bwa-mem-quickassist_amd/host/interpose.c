@@ -14,7 +14,6 @@
  * The struct mirrors are layout-compatible re-declarations (file:line cited).
  */
 #define _GNU_SOURCE
-#include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -106,33 +105,14 @@ typedef struct { /* mem_opt_t of the fork, bwamem.h:21-48 */
 typedef struct { int64_t l_pac; /* first field of bntseq_t, bntseq.h:53 */ } ref_bntseq_head_t;
 typedef struct { int l_seq; char *name, *comment, *seq, *qual, *sam; } ref_bseq1_t; /* bwa.h:18-22 */
 
-/* reference functions this shim keeps calling on the CPU (bwamem.c:283,319,395,438,495; bntseq.c) */
-extern bmh_chain_v mem_chain(const void *opt, const void *bwt, int64_t l_pac, int len, const uint8_t *seq);
-extern int mem_chain_flt(const void *opt, int n_chn, bmh_chain_t *chains);
-extern int mem_chain2aln_short(const void *opt, int64_t l_pac, const uint8_t *pac, int l_query, const uint8_t *query,
-                               const bmh_chain_t *c, bmh_alnreg_v *av);
+/* what this shim still takes from the host program: its base-code table and its clocks (bntseq.c, utils.c) */
 extern unsigned char nst_nt4_table[256];
-extern double cputime(void), realtime(void); /* utils.c */
+extern double cputime(void), realtime(void);
 
-typedef struct {
-	const ref_mem_opt_t *opt;
-	int64_t l_pac;
-	const uint8_t *pac;
-	const bmh_read_t *reads;
-	const bmh_chain_v *chains;
-} pre_ud_t;
-
-static int pre_short(void *user, int r, int ci, bmh_alnreg_v *av) /* bwamem.c:1104 */
-{
-	const pre_ud_t *u = (const pre_ud_t *)user;
-	return mem_chain2aln_short(u->opt, u->l_pac, u->pac, u->reads[r].l_seq, u->reads[r].seq, &u->chains[r].a[ci], av);
-}
-
-/* ---- seeding: the batch's FM-index queries on the GPU, the reference's own mem_chain on top -----------------------
+/* ---- seeding: the batch's FM-index queries on the GPU, chaining on top of them -----------------------------------------
  * mem_chain (bwamem.c:283) = SMEM search (smem_next2 -> bwt_smem1) + suffix-array look-ups (bwt_sa) + chaining in a
- * B-tree.  The first two are pure functions of (index, read); the shim computes them for the whole batch up front
- * (bmh_smem_batch, bmh_sa_batch) and serves them to the untouched mem_chain through interposed bwt_smem1 / bwt_sa
- * (bwt.h).  A call that is not in the batch's tables goes to the reference's own function.  BMH_SEED_BATCH=0 disables. */
+ * B-tree.  The first two are pure functions of (index, read): bmh_smem_batch and bmh_sa_batch compute them for the whole
+ * batch; bmh_chain_reads (host/chain_batch.c) then does what mem_chain and mem_chain_flt do with them. */
 typedef struct { /* bwt_t, bwt.h:45-57 */
 	uint64_t primary, L2[5], seq_len, bwt_size;
 	uint32_t *bwt;
@@ -141,7 +121,6 @@ typedef struct { /* bwt_t, bwt.h:45-57 */
 	uint64_t n_sa;
 	uint64_t *sa;
 } ref_bwt_t;
-typedef struct { size_t n, m; bmh_smem_intv_t *a; } ref_bwtintv_v; /* bwt.h:63 */
 
 typedef struct {
 	const ref_bwt_t *bwt;
@@ -153,12 +132,10 @@ typedef struct {
 	bmh_smem_intv_t *intv;
 	uint64_t *sa_k, *sa_pos; /* sorted keys and their positions */
 	size_t n_sa;
-	long long smem_hit, smem_miss, sa_hit, sa_miss;
 } qa_seed_t;
 static double g_seed_density[2] = {0.06, 0.35};
 static long long g_seed_us[3]; /* thread-microseconds: bmh_smem_batch, building the look-up keys, bmh_sa_batch */
-static __thread qa_seed_t *qa_seed; /* the batch this thread is chaining, or NULL */
-static __thread int qa_seed_cur;    /* index of the read mem_chain is working on */
+static __thread qa_seed_t *qa_seed; /* the batch this thread is chaining */
 
 static int cmp_u64(const void *a, const void *b)
 {
@@ -168,7 +145,6 @@ static int cmp_u64(const void *a, const void *b)
 
 static void qa_seed_batch_begin(bmh_ctx_t *ctx, const ref_mem_opt_t *opt, const ref_bwt_t *bwt, int n, const bmh_read_t *reads)
 {
-	const char *e = getenv("BMH_SEED_BATCH");
 	bmh_bwt_t ib;
 	bmh_smem_opt_t so;
 	qa_seed_t *S;
@@ -176,7 +152,6 @@ static void qa_seed_batch_begin(bmh_ctx_t *ctx, const ref_mem_opt_t *opt, const 
 	double ts[4];
 	int r, rc, i;
 	qa_seed = 0;
-	if (e && e[0] == '0') return;
 	ib.primary = bwt->primary, ib.seq_len = bwt->seq_len, ib.bwt_size = bwt->bwt_size, ib.bwt = bwt->bwt;
 	for (i = 0; i < 5; ++i) ib.L2[i] = bwt->L2[i];
 	ib.sa_intv = bwt->sa_intv, ib.n_sa = bwt->n_sa, ib.sa = bwt->sa;
@@ -231,67 +206,15 @@ static void qa_seed_batch_begin(bmh_ctx_t *ctx, const ref_mem_opt_t *opt, const 
 	qa_seed = S;
 }
 
-static long long g_seed_stats[4];
 static void qa_seed_batch_end(void)
 {
 	qa_seed_t *S = qa_seed;
 	qa_seed = 0;
 	if (!S) return;
-	__sync_fetch_and_add(&g_seed_stats[0], S->smem_hit), __sync_fetch_and_add(&g_seed_stats[1], S->smem_miss);
-	__sync_fetch_and_add(&g_seed_stats[2], S->sa_hit), __sync_fetch_and_add(&g_seed_stats[3], S->sa_miss);
 	free(S->call_off), free(S->calls), free(S->intv_off), free(S->intv), free(S->sa_k), free(S->sa_pos), free(S);
 }
 
-typedef int (*smem1_fn)(const void *, int, const uint8_t *, int, int, ref_bwtintv_v *, ref_bwtintv_v **);
-int bwt_smem1(const void *bwt, int len, const uint8_t *q, int x, int min_intv, ref_bwtintv_v *mem, ref_bwtintv_v *tmpvec[2])
-{
-	static smem1_fn next;
-	qa_seed_t *S = qa_seed;
-	if (S && (const void *)S->bwt == bwt && qa_seed_cur < S->n_reads && S->reads[qa_seed_cur].seq == q && S->reads[qa_seed_cur].l_seq == len) {
-		uint32_t c;
-		for (c = S->call_off[qa_seed_cur]; c < S->call_off[qa_seed_cur + 1]; ++c) {
-			const bmh_smem_call_t *cl = &S->calls[c];
-			if (cl->x == x && cl->min_intv == min_intv) {
-				if (mem->m < (size_t)cl->n) { /* kv_resize */
-					mem->m = (size_t)cl->n;
-					mem->a = (bmh_smem_intv_t *)realloc(mem->a, sizeof(bmh_smem_intv_t) * mem->m);
-				}
-				mem->n = (size_t)cl->n;
-				if (cl->n) memcpy(mem->a, &S->intv[S->intv_off[qa_seed_cur] + cl->first], sizeof(bmh_smem_intv_t) * (size_t)cl->n);
-				++S->smem_hit;
-				return cl->ret;
-			}
-		}
-		++S->smem_miss;
-	}
-	if (!next) next = (smem1_fn)dlsym(RTLD_NEXT, "bwt_smem1");
-	if (!next) bmh_tls_die("no other bwt_smem1 is loaded", BMH_E_ARG);
-	return next(bwt, len, q, x, min_intv, mem, tmpvec);
-}
-
-typedef uint64_t (*sa_fn)(const void *, uint64_t);
-uint64_t bwt_sa(const void *bwt, uint64_t k)
-{
-	static sa_fn next;
-	qa_seed_t *S = qa_seed;
-	if (S && (const void *)S->bwt == bwt) {
-		size_t lo = 0, hi = S->n_sa;
-		while (lo < hi) {
-			const size_t mid = (lo + hi) >> 1;
-			if (S->sa_k[mid] < k) lo = mid + 1;
-			else hi = mid;
-		}
-		if (lo < S->n_sa && S->sa_k[lo] == k) {
-			++S->sa_hit;
-			return S->sa_pos[lo];
-		}
-		++S->sa_miss;
-	}
-	if (!next) next = (sa_fn)dlsym(RTLD_NEXT, "bwt_sa");
-	if (!next) bmh_tls_die("no other bwt_sa is loaded", BMH_E_ARG);
-	return next(bwt, k);
-}
-
+static long long g_p1_cnt[4]; /* chains, seeds extended, seeds speculated in vain, short-chain Smith-Watermans */
 static long long g_p1_us[5]; /* phase 1, thread-microseconds: wait for a GPU slot, seeding batch, chaining (host), wait, extension batch */
 
 bmh_alnreg_v *mem_align1_core_batched(const ref_mem_opt_t *opt, const void *bwt, const ref_bntseq_head_t *bns,
@@ -302,7 +225,6 @@ bmh_alnreg_v *mem_align1_core_batched(const ref_mem_opt_t *opt, const void *bwt,
 	bmh_read_t *reads = (bmh_read_t *)malloc(sizeof(bmh_read_t) * (size_t)batch_size);
 	bmh_params_t p;
 	bmh_ctx_t *ctx;
-	pre_ud_t ud;
 	double tq[6];
 	int b, i, rc;
 
@@ -323,14 +245,22 @@ bmh_alnreg_v *mem_align1_core_batched(const ref_mem_opt_t *opt, const void *bwt,
 	bmh_pool_put(ctx);
 	gpu_leave();
 	tq[2] = realtime();
-	for (b = 0; b < batch_size; ++b) { /* chaining stays the reference's own code: bwamem.c:1095-1097 */
-		qa_seed_cur = b;
-		chn[b] = mem_chain(opt, bwt, bns->l_pac, reads[b].l_seq, reads[b].seq);
-		chn[b].n = (size_t)mem_chain_flt(opt, (int)chn[b].n, chn[b].a);
+	{ /* chaining: mem_chain + mem_chain_flt (bwamem.c:1095-1097) over the batch's tables */
+		const qa_seed_t *S = qa_seed;
+		bmh_chain_opt_t co;
+		co.w = opt->w, co.max_chain_gap = opt->max_chain_gap, co.min_seed_len = opt->min_seed_len, co.max_occ = opt->max_occ;
+		co.split_len = (int)(opt->min_seed_len * opt->split_factor + .499), co.split_width = opt->split_width;
+		co.mask_level = opt->mask_level, co.chain_drop_ratio = opt->chain_drop_ratio;
+		if ((rc = bmh_chain_reads(&co, bns->l_pac, batch_size, reads, S->call_off, S->calls, S->intv_off, S->intv, S->sa_k, S->sa_pos, S->n_sa, chn)))
+			bmh_tls_die("the batch's seeding tables do not cover its chaining", rc);
+		{
+			long long nc = 0;
+			for (b = 0; b < batch_size; ++b) nc += (long long)chn[b].n;
+			__sync_fetch_and_add(&g_p1_cnt[0], nc);
+		}
 	}
 	qa_seed_batch_end();
 	tq[3] = realtime();
-	ud.opt = opt, ud.l_pac = bns->l_pac, ud.pac = pac, ud.reads = reads, ud.chains = chn;
 	gpu_enter();
 	tq[4] = realtime();
 	ctx = bmh_pool_get(&p);
@@ -339,8 +269,14 @@ bmh_alnreg_v *mem_align1_core_batched(const ref_mem_opt_t *opt, const void *bwt,
 		const char *e = getenv("BMH_PAC_RESIDENT");
 		if (!(e && e[0] == '0') && (rc = bmh_ctx_set_pac(ctx, pac, bns->l_pac))) bmh_tls_die(bmh_last_error(ctx), rc);
 	}
-	if ((rc = bmh_chain2aln_batch(ctx, bns->l_pac, pac, batch_size, reads, chn, pre_short, &ud, regs))) /* bwamem.c:1110 */
+	if ((rc = bmh_chains2regs_batch(ctx, bns->l_pac, pac, batch_size, reads, chn, opt->min_seed_len, regs))) /* bwamem.c:1101-1110 */
 		bmh_tls_die(bmh_last_error(ctx), rc);
+	{
+		bmh_driver_stats_t st;
+		bmh_driver_stats(ctx, &st);
+		__sync_fetch_and_add(&g_p1_cnt[1], st.seeds_extended), __sync_fetch_and_add(&g_p1_cnt[2], st.seeds_speculated);
+		__sync_fetch_and_add(&g_p1_cnt[3], st.short_sw);
+	}
 	bmh_pool_put(ctx);
 	gpu_leave();
 	tq[5] = realtime();
@@ -549,8 +485,8 @@ void mem_process_seqs(const ref_mem_opt_t *opt, const void *bwt, const ref_bntse
 		        g_seed_us[0] * 1e-6, g_seed_us[1] * 1e-6, g_seed_us[2] * 1e-6);
 		fprintf(stderr, "[bwamem_hip] phase 1 thread-seconds so far: wait %.3f, seeding batch %.3f, chaining on the host %.3f, wait %.3f, extension batch %.3f\n",
 		        g_p1_us[0] * 1e-6, g_p1_us[1] * 1e-6, g_p1_us[2] * 1e-6, g_p1_us[3] * 1e-6, g_p1_us[4] * 1e-6);
-		fprintf(stderr, "[bwamem_hip] seeding: bwt_smem1 %lld from the batch / %lld on the host, bwt_sa %lld / %lld\n", g_seed_stats[0],
-		        g_seed_stats[1], g_seed_stats[2], g_seed_stats[3]);
+		fprintf(stderr, "[bwamem_hip] phase 1 so far: %lld chains from bmh_chain_reads, %lld seeds extended (+%lld speculated in vain), %lld short-chain Smith-Watermans batched\n",
+		        g_p1_cnt[0], g_p1_cnt[1], g_p1_cnt[2], g_p1_cnt[3]);
 		fprintf(stderr, "[bwamem_hip] phase 2 thread-seconds so far: wait %.3f, bmh_sam_batch %.3f\n", g_sam_us[0] * 1e-6, g_sam_us[1] * 1e-6);
 		fprintf(stderr, "[bwamem_hip] chunk of %d reads: phase 1 %.3f s, pestat + mate rescue %.3f s, phase 2 (marking, pairing, global alignments, SAM) %.3f s\n", n,
 		        t_[1] - t_[0], t_[2] - t_[1], t_[3] - t_[2]);

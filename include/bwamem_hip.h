@@ -266,6 +266,13 @@ int bmh_chain2aln_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n
                         const bmh_read_t *reads, const bmh_chain_v *chains, bmh_chain_pre_fn pre,
                         void *pre_user, bmh_alnreg_v *regs);
 
+/* The whole loop body of mem_align1_core (bwamem.c:1101-1107 / :1136-1143) for n_reads reads: per chain first
+ * mem_chain2aln_short (bwamem.c:495-542) -- its qualifying tests on the host, the ksw_align2 calls of all chains of the
+ * batch as ONE bmh_sw_batch, its verdict folded in where the reference calls it -- then, unless that settled the chain,
+ * mem_chain2aln as in bmh_chain2aln_batch.  min_seed_len = opt->min_seed_len (the XSUBO threshold, bwamem.c:529). */
+int bmh_chains2regs_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n_reads, const bmh_read_t *reads,
+                          const bmh_chain_v *chains, int min_seed_len, bmh_alnreg_v *regs);
+
 /* ---- L3, phase 2: the caller of ksw_global2.
  * One request = one alignment region after bwa_fix_xref2, as mem_reg2aln sees it at bwamem.c:1187. */
 typedef struct bmh_cigar_req {
@@ -302,6 +309,7 @@ typedef struct bmh_driver_stats {
 	int64_t rounds, ext_tasks, seeds_extended, seeds_skipped;
 	int64_t pool_bytes; /* bytes of sequence shipped to the device for the call */
 	int64_t seeds_speculated; /* seeds the device extended ahead of the replay whose result was not needed */
+	int64_t short_sw;         /* ksw_align2 calls of mem_chain2aln_short run as one batch (bmh_chains2regs_batch) */
 } bmh_driver_stats_t;
 int bmh_driver_stats(const bmh_ctx_t *ctx, bmh_driver_stats_t *st);
 
@@ -490,6 +498,25 @@ int bmh_smem_batch(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const b
                    bmh_smem_call_t *calls, size_t call_cap, uint64_t *intv_off, bmh_smem_intv_t *intv, size_t intv_cap);
 /* N x bwt_sa: pos[i] = position (doubled coordinate) of suffix-array entry k[i]. */
 int bmh_sa_batch(bmh_ctx_t *ctx, const uint64_t *k, int64_t n, uint64_t *pos);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Seeds to chains (the rest of SURVEY.md §8(f) row 3): host code over the results of bmh_smem_batch / bmh_sa_batch.
+ * Replaces: mem_chain (reference bwamem.c:283-306) = smem_next2's rounds (:118-157) + mem_insert_seed (:208-243, over
+ *           test_and_merge :186-206 and klib's B-tree of chains) + the in-order read-out, followed by mem_chain_flt
+ *           (:319-380) -- lines bwamem.c:1096-1097 of mem_align1_core_batched.
+ * call_off / calls / intv_off / intv are bmh_smem_batch's outputs for the same reads.  sa_k (ascending, unique) and
+ * sa_pos are a table of bwt_sa results that covers every occurrence x[0]..x[0]+x[2]-1 of every interval with length
+ * >= min_seed_len and x[2] <= max_occ (BMH_E_ARG if an entry is missing).  chains[r] is filled like mem_chain's return
+ * value: a malloc'd array of chains in the reference's order, each with a malloc'd seed array; the caller frees both. */
+typedef struct bmh_chain_opt { /* the mem_opt_t fields seeding + chaining read (bwamem.h:21-48) */
+	int32_t w, max_chain_gap, min_seed_len, max_occ;
+	int32_t split_len;   /* (int)(min_seed_len * split_factor + .499), bwamem.c:211 */
+	int32_t split_width;
+	float mask_level, chain_drop_ratio;
+} bmh_chain_opt_t;
+int bmh_chain_reads(const bmh_chain_opt_t *o, int64_t l_pac, int n_reads, const bmh_read_t *reads, const uint32_t *call_off,
+                    const bmh_smem_call_t *calls, const uint64_t *intv_off, const bmh_smem_intv_t *intv, const uint64_t *sa_k,
+                    const uint64_t *sa_pos, size_t n_sa, bmh_chain_v *chains);
 
 #ifdef __cplusplus
 }
