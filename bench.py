@@ -112,9 +112,11 @@ def pipeline_baseline(n_reads, genome_bp, threads, batch=8192, noisy=0.3, dut=Tr
         for m in re.finditer(r"Processed (\d+) reads in ([\d.]+) CPU sec, ([\d.]+) real sec", err):
             reads += int(m.group(1))
             real += float(m.group(3))
-        miss = re.findall(r"served (\d+) calls from the batch, (\d+) went to the host", err)
+        chunks = [l.split("] ", 1)[1] for l in err.splitlines() if l.startswith("[bwamem_hip] chunk of")]
+        tail = [l.split("] ", 1)[1] for l in err.splitlines() if l.startswith(("[bwamem_hip] phase", "[bwamem_hip] seeding batch", "[bwamem_hip] mate rescue"))]
+        drv = [l.split("] ", 1)[1] for l in err.splitlines() if l.startswith(("[bwamem_hip] bmh_sam_batch", "[bwamem_hip] bmh_reg2cigar_batch", "[bwamem_hip] bmh_chain2aln_batch"))]
         return {"reads": reads, "real_s": real, "reads_per_s": reads / real if real else None, "wall_s": time.time() - t0,
-                "cigar_table": {"served": int(miss[-1][0]), "to_host": int(miss[-1][1])} if miss else None}
+                "chunks": chunks[:8] if preload else None, "thread_seconds": tail[-5:] if preload else None, "driver_trace": drv[-48:-40] + drv[-6:] if drv else None}
 
     if dut:
         run(True, os.path.join(tmp, "warm.sam"), min(threads, 16))  # page the HIP runtime + code objects in (seconds on a fresh box)
@@ -166,11 +168,14 @@ def main():
     ap.add_argument("--global-per-read", type=float, default=0.85, help="ksw_global2 tasks per read (measured, SURVEY.md §8a2)")
     ap.add_argument("--rescue-rate", type=float, default=0.06, help="ksw_align2 mate-rescue tasks per pair (measured 0.02-0.11)")
     ap.add_argument("--rescue-batch", type=int, default=1_000_000, help="mate-rescue tasks are collected over chunks into batches of up to this many")
-    ap.add_argument("--streams", type=int, default=1, help="1: the three stages of a chunk back to back on one stream; 3: one context and stream per stage")
+    ap.add_argument("--streams", type=int, default=3, choices=[1, 3],
+                    help="3: one context and HIP stream per stage, so chunk k's global alignments run beside chunk k+1's extensions "
+                         "(measured +10 %% reads/s); 1: the stages back to back on one stream (every kernel alone on the chip)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the oracle-port CPU baseline (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline-baseline", action="store_true")
-    ap.add_argument("--pipeline-reads", type=int, default=400_000)
+    ap.add_argument("--pipeline-reads", type=int, default=3_200_000, help="reads of the whole-pipeline baseline (three chunks of bwa's at 16 threads)")
+    ap.add_argument("--pipeline-batch", type=int, default=32768, help="the fork's -b: reads per phase-1 batch")
     ap.add_argument("--pipeline-genome", type=int, default=4_600_000)
     args, rest = ap.parse_known_args()
     if args.workload == "se1m":
@@ -190,7 +195,7 @@ def main():
     pipe = None
     if world == 1 and rank == 0 and not args.no_pipeline_baseline and args.pipeline_reads > 0:
         try:
-            pipe = pipeline_baseline(args.pipeline_reads, args.pipeline_genome, ncores)
+            pipe = pipeline_baseline(args.pipeline_reads, args.pipeline_genome, ncores, batch=args.pipeline_batch)
             pipe["cores_note"] = cores_note
         except Exception as e:  # a baseline must never take the measurement down with it
             pipe = {"skipped": f"{type(e).__name__}: {e}"}

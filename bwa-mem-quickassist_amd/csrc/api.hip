@@ -13,6 +13,8 @@
 
 namespace bmh {
 
+bmh_gate_fn g_gate_enter = nullptr, g_gate_leave = nullptr;
+
 int set_hip_error(bmh_ctx *ctx, hipError_t e, const char *what)
 {
 	if (ctx) {
@@ -130,6 +132,13 @@ using namespace bmh;
 extern "C" {
 
 int bmh_version(void) { return BMH_VERSION; }
+
+int bmh_set_device_gate(bmh_gate_fn enter, bmh_gate_fn leave)
+{
+	if ((enter == nullptr) != (leave == nullptr)) return BMH_E_ARG;
+	g_gate_enter = enter, g_gate_leave = leave;
+	return BMH_OK;
+}
 
 const char *bmh_strerror(int code)
 {
@@ -471,6 +480,7 @@ int bmh_extend_batch(bmh_ctx_t *ctx, const uint8_t *pool, size_t pool_bytes, con
 	}
 	int qmax = 1, rc;
 	if ((rc = validate_ext(ctx, tasks, n, pool_bytes, &qmax))) return rc;
+	GateGuard gate;
 	BMH_HIP(ctx, hipSetDevice(ctx->device));
 	if (!resident) {
 		ctx->pool_resident = false;
@@ -496,6 +506,7 @@ int bmh_upload_pool(bmh_ctx_t *ctx, const uint8_t *pool, size_t bytes)
 {
 	if (!ctx || !pool) return BMH_E_ARG;
 	int rc;
+	GateGuard gate;
 	BMH_HIP(ctx, hipSetDevice(ctx->device));
 	ctx->pool_resident = false;
 	if ((rc = ensure(ctx, ctx->d_pool, bytes + 16))) return rc;
@@ -530,18 +541,34 @@ int bmh_extend_batch_sharded(bmh_ctx_t *const *ctxs, int n_ctx, const uint8_t *p
 		if (m == 0) continue;
 		const bmh_ext_task_t *t = tasks + lo[(size_t)g];
 		int qmax = 1;
-		if ((rc = validate_ext(c, t, m, pool_bytes, &qmax))) return rc;
-		BMH_HIP(c, hipSetDevice(c->device));
-		if ((rc = ensure(c, c->d_pool, pool_bytes + 16))) return rc;
-		if ((rc = ensure(c, c->d_tasks, (size_t)m * sizeof(bmh_ext_task_t)))) return rc;
-		if ((rc = ensure(c, c->d_res, (size_t)m * sizeof(bmh_ext_result_t)))) return rc;
-		BMH_HIP(c, hipMemcpyAsync(c->d_pool.p, pool, pool_bytes, hipMemcpyHostToDevice, c->stream));
-		BMH_HIP(c, hipMemcpyAsync(c->d_tasks.p, t, (size_t)m * sizeof(bmh_ext_task_t), hipMemcpyHostToDevice, c->stream));
-		if ((rc = launch_extend(c, (const uint8_t *)c->d_pool.p, (const bmh_ext_task_t *)c->d_tasks.p, m,
-		                        (bmh_ext_result_t *)c->d_res.p, nullptr, qmax)))
+		if ((rc = validate_ext(c, t, m, pool_bytes, &qmax))) {
+			for (int h = 0; h < g; ++h) {
+				(void)hipSetDevice(ctxs[h]->device);
+				(void)hipStreamSynchronize(ctxs[h]->stream);
+			}
 			return rc;
-		BMH_HIP(c, hipMemcpyAsync(results + lo[(size_t)g], c->d_res.p, (size_t)m * sizeof(bmh_ext_result_t),
-		                          hipMemcpyDeviceToHost, c->stream));
+		}
+		BMH_HIP(c, hipSetDevice(c->device));
+		c->pool_resident = false; // the context's pool is overwritten below
+		rc = BMH_OK;
+		if (!rc) rc = ensure(c, c->d_pool, pool_bytes + 16);
+		if (!rc) rc = ensure(c, c->d_tasks, (size_t)m * sizeof(bmh_ext_task_t));
+		if (!rc) rc = ensure(c, c->d_res, (size_t)m * sizeof(bmh_ext_result_t));
+		if (!rc && hipMemcpyAsync(c->d_pool.p, pool, pool_bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = BMH_E_HIP;
+		if (!rc && hipMemcpyAsync(c->d_tasks.p, t, (size_t)m * sizeof(bmh_ext_task_t), hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = BMH_E_HIP;
+		if (!rc)
+			rc = launch_extend(c, (const uint8_t *)c->d_pool.p, (const bmh_ext_task_t *)c->d_tasks.p, m, (bmh_ext_result_t *)c->d_res.p, nullptr,
+			                   qmax);
+		if (!rc && hipMemcpyAsync(results + lo[(size_t)g], c->d_res.p, (size_t)m * sizeof(bmh_ext_result_t), hipMemcpyDeviceToHost, c->stream) !=
+		               hipSuccess)
+			rc = BMH_E_HIP;
+		if (rc) { // copies into the caller's `results` may be in flight on the devices already served: drain them first
+			for (int h = 0; h <= g; ++h) {
+				(void)hipSetDevice(ctxs[h]->device);
+				(void)hipStreamSynchronize(ctxs[h]->stream);
+			}
+			return rc;
+		}
 	}
 	int first = BMH_OK;
 	for (int g = 0; g < n_ctx; ++g) {
@@ -645,6 +672,7 @@ int bmh_seedext_batch(bmh_ctx_t *ctx, const uint8_t *pool, size_t pool_bytes, co
 	if (n == 0) return BMH_OK;
 	int rc;
 	if (pool && (rc = bmh_upload_pool(ctx, pool, pool_bytes))) return rc;
+	GateGuard gate;
 	if ((rc = bmh_seedext_submit(ctx, tasks, n))) return rc;
 	return bmh_seedext_wait(ctx, results);
 }
@@ -667,7 +695,7 @@ int bmh_global_batch_device(bmh_ctx_t *ctx, const uint8_t *d_pool, const bmh_glb
 	BMH_HIP(ctx, hipSetDevice(ctx->device));
 	// no host view of the tasks: size for the context's capacity hint (square band-limited matrix)
 	return launch_global(ctx, d_pool, d_tasks, n, d_res, d_cigar, d_order, ctx->qcap, ctx->qcap + 2 * ctx->params.w + 64,
-	                     std::max(ctx->params.w * 4, 100));
+	                     std::max(ctx->params.w * 4, 100), std::max(ctx->params.w * 4, 100));
 }
 
 int bmh_global_batch(bmh_ctx_t *ctx, const uint8_t *pool, size_t pool_bytes, const bmh_glb_task_t *tasks, int64_t n,
@@ -682,7 +710,7 @@ int bmh_global_batch(bmh_ctx_t *ctx, const uint8_t *pool, size_t pool_bytes, con
 		if (!ctx->pool_resident) return BMH_E_ARG;
 		pool_bytes = ctx->pool_bytes;
 	}
-	int qmax = 1, tmax = 1, wmax = 0, rc;
+	int qmax = 1, tmax = 1, wmax = 0, wraw = 0, rc;
 	for (int64_t k = 0; k < n; ++k) {
 		const bmh_glb_task_t &x = tasks[k];
 		if (x.q_off + x.qlen > pool_bytes || x.t_off + x.tlen > pool_bytes || x.w < 0 ||
@@ -692,7 +720,9 @@ int bmh_global_batch(bmh_ctx_t *ctx, const uint8_t *pool, size_t pool_bytes, con
 		}
 		qmax = std::max(qmax, (int)x.qlen), tmax = std::max(tmax, (int)x.tlen);
 		wmax = std::max(wmax, std::min(x.w, (int)x.qlen)); // only min(qlen,2w+1) columns are ever stored
+		wraw = std::max(wraw, x.w);                        // ... but the device bins the tasks by their w as given
 	}
+	GateGuard gate;
 	BMH_HIP(ctx, hipSetDevice(ctx->device));
 	if (!resident) {
 		ctx->pool_resident = false;
@@ -708,7 +738,7 @@ int bmh_global_batch(bmh_ctx_t *ctx, const uint8_t *pool, size_t pool_bytes, con
 	if (!resident && (rc = st.h2d(ctx->d_pool.p, pool, pool_bytes))) return rc;
 	if ((rc = st.h2d(ctx->d_tasks.p, tasks, (size_t)n * sizeof(bmh_glb_task_t)))) return rc;
 	if ((rc = launch_global(ctx, (const uint8_t *)ctx->d_pool.p, (const bmh_glb_task_t *)ctx->d_tasks.p, n,
-	                        (bmh_glb_result_t *)ctx->d_res.p, (uint32_t *)ctx->d_cigar.p, nullptr, qmax, tmax, wmax)))
+	                        (bmh_glb_result_t *)ctx->d_res.p, (uint32_t *)ctx->d_cigar.p, nullptr, qmax, tmax, wmax, wraw)))
 		return rc;
 	if ((rc = st.d2h(results, ctx->d_res.p, (size_t)n * sizeof(bmh_glb_result_t)))) return rc;
 	if (cigar_words && (rc = st.d2h(cigar_pool, ctx->d_cigar.p, cigar_words * 4))) return rc;
@@ -764,6 +794,7 @@ int bmh_sw_batch(bmh_ctx_t *ctx, const uint8_t *pool, size_t pool_bytes, const b
 		}
 		qmax = std::max(qmax, (int)x.qlen), tmax = std::max(tmax, (int)x.tlen);
 	}
+	GateGuard gate;
 	BMH_HIP(ctx, hipSetDevice(ctx->device));
 	if (!resident) {
 		ctx->pool_resident = false;

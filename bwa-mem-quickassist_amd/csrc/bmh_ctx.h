@@ -82,6 +82,22 @@ struct bmh_ctx {
 
 namespace bmh {
 
+// the caller's gate around a device section (bmh_set_device_gate), held for the lifetime of the guard
+extern bmh_gate_fn g_gate_enter, g_gate_leave;
+struct GateGuard {
+	bmh_gate_fn leave;
+	GateGuard() : leave(g_gate_leave)
+	{
+		if (g_gate_enter) g_gate_enter();
+	}
+	~GateGuard()
+	{
+		if (leave) leave();
+	}
+	GateGuard(const GateGuard &) = delete;
+	GateGuard &operator=(const GateGuard &) = delete;
+};
+
 int set_hip_error(bmh_ctx *ctx, hipError_t e, const char *what);
 int ensure(bmh_ctx *ctx, DevBuf &b, size_t bytes);
 int ensure_host(bmh_ctx *ctx, DevBuf &b, size_t bytes); // same, pinned host memory
@@ -132,8 +148,10 @@ int launch_extend_lane(bmh_ctx *ctx, int c, const uint8_t *d_pool, const bmh_ext
                        bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, bool exact);
 int launch_extend_reg(bmh_ctx *ctx, int ns, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
                       bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, int max_count = 0, long long grid_cap = 0);
+// wmax: the widest band in stored columns (min(w, qlen)), sizes the wave kernel's direction matrix; wgate: the largest w
+// as the tasks carry it -- the device bins by that, so it decides which lane kernels are launched
 int launch_global(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_glb_task_t *d_tasks, int64_t n,
                   bmh_glb_result_t *d_res, uint32_t *d_cigar, const uint32_t *d_order, int qmax, int tmax,
-                  int wmax);
+                  int wmax, int wgate);
 
 } // namespace bmh

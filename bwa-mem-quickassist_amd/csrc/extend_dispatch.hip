@@ -175,6 +175,25 @@ static int hint_post(bmh_ctx *ctx, int kind, const uint32_t *d_counts)
 	return BMH_OK;
 }
 
+// a list whose length lives on the device and that the last launch of this kind found (almost) empty -- the band-doubling
+// retries of the fused per-seed pipeline, for reads that need none: no sort, no bins, ONE launch of the any-length kernel
+// (one wave per task) over the list as it stands.  Correct for any count; a count that has grown shows in the next hint.
+constexpr uint32_t kTinyList = 2048;
+static int launch_extend_tiny(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n, bmh_ext_result_t *d_res,
+                              const uint32_t *d_order, int qmax, const uint32_t *d_n, int kind)
+{
+	bmh_ctx::BinHint &h = ctx->hint[kind];
+	int rc = launch_extend_lds(ctx, d_pool, d_tasks, n, d_res, d_order, d_n, qmax, 2 * kTinyList);
+	if (rc) return rc;
+	if (!h.pending && h.h) { // the list length stands in for the bin counts: it is all the next decision needs
+		for (int b = 0; b < 8; ++b) h.h[b] = 0;
+		BMH_HIP(ctx, hipMemcpyAsync(h.h + 5, d_n, 4, hipMemcpyDeviceToHost, ctx->stream));
+		BMH_HIP(ctx, hipEventRecord(h.ev, ctx->stream));
+		h.pending = true;
+	}
+	return BMH_OK;
+}
+
 int launch_extend(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
                   bmh_ext_result_t *d_res, const uint32_t *d_order, int qmax, const uint32_t *d_n, int kind)
 {
@@ -183,6 +202,11 @@ int launch_extend(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_t
 	if (kind < 0 || kind >= bmh_ctx::kHintKinds) kind = 0;
 	hint_poll(ctx, kind);
 	const bmh_ctx::BinHint &hint = ctx->hint[kind];
+	if (d_n && hint.valid && !ctx->ext_mode_forced) {
+		uint32_t tot = 0;
+		for (int b = 0; b < kExtBins; ++b) tot += hint.cnt[b];
+		if (tot <= kTinyList) return launch_extend_tiny(ctx, d_pool, d_tasks, n, d_res, d_order, qmax, d_n, kind);
+	}
 	// expected size of bin b: the previous launch's count with a margin -- or, with no hint, the whole batch
 	int64_t est[kExtBins], est_total = 0;
 	for (int b = 0; b < kExtBins; ++b) {

@@ -460,11 +460,13 @@ int bmh_ctx_set_bwt(bmh_ctx_t *ctx, const bmh_bwt_t *b)
 		const size_t bw = (size_t)b->bwt_size * 4 + 64, sb = (size_t)b->n_sa * 8 + 64;
 		if (hipMalloc(&n.d_bwt, bw) != hipSuccess || hipMalloc(&n.d_sa, sb) != hipSuccess) {
 			(void)hipGetLastError();
+			if (n.d_bwt) (void)hipFree(n.d_bwt);
 			ctx->last_error = "hipMalloc for the FM-index failed";
 			return BMH_E_NOMEM;
 		}
 		if (hipMemcpy(n.d_bwt, b->bwt, (size_t)b->bwt_size * 4, hipMemcpyHostToDevice) != hipSuccess ||
 		    hipMemcpy(n.d_sa, b->sa, (size_t)b->n_sa * 8, hipMemcpyHostToDevice) != hipSuccess) {
+			(void)hipFree(n.d_bwt), (void)hipFree(n.d_sa);
 			ctx->last_error = "uploading the FM-index failed";
 			return BMH_E_HIP;
 		}
@@ -496,6 +498,7 @@ int bmh_sa_batch(bmh_ctx_t *ctx, const uint64_t *k, int64_t n, uint64_t *pos)
 			ctx->last_error = "suffix-array index " + std::to_string(i) + " is beyond the index";
 			return BMH_E_ARG;
 		}
+	GateGuard gate;
 	int rc;
 	BMH_HIP(ctx, hipSetDevice(ctx->device));
 	if ((rc = ensure(ctx, ctx->d_tasks, (size_t)n * 8)) || (rc = ensure(ctx, ctx->d_res, (size_t)n * 8))) return rc;
@@ -535,6 +538,7 @@ int bmh_smem_batch(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const b
 		if (reads[r].l_seq < 0 || (reads[r].l_seq > 0 && !reads[r].seq)) return BMH_E_ARG;
 		bytes += (size_t)reads[r].l_seq, lmax = std::max(lmax, reads[r].l_seq);
 	}
+	GateGuard gate;
 	BMH_HIP(ctx, hipSetDevice(ctx->device));
 	ctx->pool_resident = false;
 	// host image of the input block [reads | offsets | lengths], built in pinned memory and uploaded with one copy

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void glb_sort_hist_kernel(const bmh_glb_task_t
 
 int launch_global(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_glb_task_t *d_tasks, int64_t n,
                   bmh_glb_result_t *d_res, uint32_t *d_cigar, const uint32_t *d_order, int qmax, int tmax,
-                  int wmax)
+                  int wmax, int wgate)
 {
 	if (n <= 0) return BMH_OK;
 	int rc;
@@ -264,7 +264,7 @@ int launch_global(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_glb_task_t *d_t
 		if (tm) BMH_HIP(ctx, hipEventRecord(ctx->ev_gbin[0], ctx->stream));
 		if ((rc = launch_global_lane(ctx, 64, d_pool, d_tasks, n, d_res, d_cigar, lists, counts + 0, rows_cap))) return rc;
 		if (tm) BMH_HIP(ctx, hipEventRecord(ctx->ev_gbin[1], ctx->stream));
-		if (wmax > 31 && (rc = launch_global_lane(ctx, 128, d_pool, d_tasks, n, d_res, d_cigar, lists + N, counts + 1, rows_cap)))
+		if (wgate > 31 && (rc = launch_global_lane(ctx, 128, d_pool, d_tasks, n, d_res, d_cigar, lists + N, counts + 1, rows_cap)))
 			return rc;
 	}
 	if (tm) BMH_HIP(ctx, hipEventRecord(ctx->ev_gbin[2], ctx->stream));

@@ -237,13 +237,14 @@ int launch_global_lane(bmh_ctx *ctx, int c, const uint8_t *d_pool, const bmh_glb
 	int ncu = 256;
 	(void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device);
 	long long grid = (n + 63) / 64;
-	const long long resident = (long long)ncu * 4 * (c <= 64 ? BMH_GL_WAVES64 : BMH_GL_WAVES128) * 2; // persistent: ~2x the resident waves
+	// persistent grid = the waves that are resident at once: every wave owns a private direction slab for as long as it
+	// lives, so more blocks than that would only pin more HBM (2 048 waves x 170 rows x 8 blocks x 256 B = 0.7 GB at
+	// 150 bp; a grow-only workspace per context, and the preload shim keeps one context per host thread)
+	const long long resident = (long long)ncu * 4 * (c <= 64 ? BMH_GL_WAVES64 : BMH_GL_WAVES128);
 	if (grid > resident) grid = resident;
-	// one slab serves both lane kernels of a launch (they run back to back on the stream): size it for the larger one
-	// (and for the waves this launch can actually have in flight: a context that only ever sees small batches must not
-	// pin gigabytes)
-	const size_t slab_waves = (size_t)std::min<long long>((n + 63) / 64, (long long)ncu * 4 * 2 * 2);
-	const size_t slab = slab_waves * (size_t)rows_cap * (size_t)(128 / 8) * 64 * 4; // [block][row][lane] dwords, 8 cells each
+	// one slab serves both lane kernels of a launch (they run back to back on the stream): [block][row][lane] dwords of
+	// 8 cells, C/8 blocks per row
+	const size_t slab = (size_t)grid * (size_t)rows_cap * (size_t)(c / 8) * 64 * 4;
 	int rc = ensure(ctx, ctx->d_zslab, slab);
 	if (rc) return rc;
 #define BMH_LAUNCH_GL(CC)                                                                                             \

@@ -241,39 +241,47 @@ static int chain_flt(const bmh_chain_opt_t *o, int n_chn, bmh_chain_t *chains)
 }
 
 /* ---- one round of smem_next2 (bwamem.c:118-157) from the batch's call records: the intervals it returns */
-typedef struct {
-	bmh_smem_intv_t *a;
+typedef struct { /* a merged round: pointers into the batch's interval array (their index finds their bwt_sa results) */
+	const bmh_smem_intv_t **a;
 	size_t n, m;
 } intv_v;
 static inline void iv_push(intv_v *v, const bmh_smem_intv_t *x)
 {
 	if (v->n == v->m) {
 		v->m = v->m ? v->m << 1 : 64;
-		v->a = (bmh_smem_intv_t *)realloc(v->a, sizeof(bmh_smem_intv_t) * v->m);
+		v->a = (const bmh_smem_intv_t **)realloc((void *)v->a, sizeof(*v->a) * v->m);
 	}
-	v->a[v->n++] = *x;
+	v->a[v->n++] = x;
 }
 static inline int iv_len(const bmh_smem_intv_t *p) { return (int)((uint32_t)p->info - (uint32_t)(p->info >> 32)); }
 
-static uint64_t sa_lookup(const uint64_t *keys, const uint64_t *pos, size_t n, uint64_t k, int *found)
+/* The suffix-array entries chaining will ask for (bwamem.c:218-225): every occurrence of every interval that is long
+ * and rare enough -- taken over ALL intervals the batch returned, a superset of the merged lists that are walked.
+ * sa_off[k] = index of interval k's first entry in the key list (and later in the position list), or UINT64_MAX for an
+ * interval that is never looked up; keys (nullable: count only) receives x[0] + j for j < x[2].  Returns the key count. */
+uint64_t bmh_chain_sa_keys(const bmh_chain_opt_t *o, uint64_t n_intv, const bmh_smem_intv_t *intv, uint64_t *sa_off, uint64_t *keys)
 {
-	size_t lo = 0, hi = n;
-	while (lo < hi) {
-		const size_t mid = (lo + hi) >> 1;
-		if (keys[mid] < k) lo = mid + 1;
-		else hi = mid;
+	uint64_t k, n = 0;
+	for (k = 0; k < n_intv; ++k) {
+		const bmh_smem_intv_t *p = &intv[k];
+		if (iv_len(p) >= o->min_seed_len && p->x[2] <= (uint64_t)o->max_occ) {
+			uint64_t j;
+			if (sa_off) sa_off[k] = n;
+			if (keys)
+				for (j = 0; j < p->x[2]; ++j) keys[n + j] = p->x[0] + j;
+			n += p->x[2];
+		} else if (sa_off) sa_off[k] = UINT64_MAX;
 	}
-	*found = lo < n && keys[lo] == k;
-	return *found ? pos[lo] : 0;
+	return n;
 }
 
 int bmh_chain_reads(const bmh_chain_opt_t *o, int64_t l_pac, int n_reads, const bmh_read_t *reads, const uint32_t *call_off,
-                    const bmh_smem_call_t *calls, const uint64_t *intv_off, const bmh_smem_intv_t *intv, const uint64_t *sa_k,
-                    const uint64_t *sa_pos, size_t n_sa, bmh_chain_v *chains)
+                    const bmh_smem_call_t *calls, const uint64_t *intv_off, const bmh_smem_intv_t *intv, const uint64_t *sa_off,
+                    const uint64_t *sa_pos, bmh_chain_v *chains)
 {
 	intv_v merged = {0, 0, 0};
 	int r, rc = BMH_OK;
-	if (!o || n_reads < 0 || (n_reads > 0 && (!reads || !call_off || !calls || !intv_off || !intv || !chains))) return BMH_E_ARG;
+	if (!o || n_reads < 0 || (n_reads > 0 && (!reads || !call_off || !calls || !intv_off || !intv || !sa_off || !sa_pos || !chains))) return BMH_E_ARG;
 	for (r = 0; r < n_reads; ++r) {
 		const int len = reads[r].l_seq;
 		const bmh_smem_intv_t *iv = intv + intv_off[r];
@@ -287,7 +295,8 @@ int bmh_chain_reads(const bmh_chain_opt_t *o, int64_t l_pac, int n_reads, const 
 		bt.root = bt_node(&bt);
 		while (c < call_off[r + 1]) { /* one smem_next2 round per main bwt_smem1 call */
 			const bmh_smem_call_t *mc = &calls[c++];
-			const bmh_smem_intv_t *m = iv + mc->first, *list = m;
+			const bmh_smem_intv_t *m = iv + mc->first;
+			const bmh_smem_intv_t **list = 0; /* null: the main call's intervals as they stand */
 			size_t n_list = (size_t)mc->n, i;
 			int max = 0, max_i = 0;
 			for (i = 0; i < (size_t)mc->n; ++i) /* the longest match, bwamem.c:130-134 */
@@ -320,16 +329,16 @@ int bmh_chain_reads(const bmh_chain_opt_t *o, int64_t l_pac, int n_reads, const 
 				list = merged.a, n_list = merged.n;
 			}
 			for (i = 0; i < n_list; ++i) { /* mem_insert_seed's loop body, bwamem.c:216-240 */
-				const bmh_smem_intv_t *p = &list[i];
+				const bmh_smem_intv_t *p = list ? list[i] : &m[i];
 				const int slen = iv_len(p);
 				uint64_t kk;
 				if (slen < o->min_seed_len || p->x[2] > (uint64_t)o->max_occ) continue;
+				if (sa_off[(size_t)(p - intv)] == UINT64_MAX) { rc = BMH_E_ARG; goto fail; } /* the caller's table must cover every such interval */
 				for (kk = 0; kk < p->x[2]; ++kk) {
 					bmh_chain_t tmp, *lower;
 					bmh_seed_t sd;
-					int found, to_add = 0;
-					sd.rbeg = tmp.pos = (int64_t)sa_lookup(sa_k, sa_pos, n_sa, p->x[0] + kk, &found);
-					if (!found) { rc = BMH_E_ARG; goto fail; } /* the caller's table must cover every such entry */
+					int to_add = 0;
+					sd.rbeg = tmp.pos = (int64_t)sa_pos[sa_off[(size_t)(p - intv)] + kk];
 					sd.qbeg = (int32_t)(p->info >> 32), sd.len = slen;
 					if (sd.rbeg < l_pac && l_pac < sd.rbeg + sd.len) continue; /* bridges the strands */
 					if (bt.n_keys) {
@@ -363,6 +372,6 @@ int bmh_chain_reads(const bmh_chain_opt_t *o, int64_t l_pac, int n_reads, const 
 		free(bt.all);
 		break;
 	}
-	free(merged.a);
+	free((void *)merged.a);
 	return rc;
 }

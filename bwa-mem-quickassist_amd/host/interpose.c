@@ -48,7 +48,7 @@ static void *prewarm_thread(void *arg)
 {
 	const char *e = getenv("BMH_GPU_CONCURRENCY");
 	(void)arg;
-	bmh_pool_prewarm(e && atoi(e) > 0 ? atoi(e) : 8);
+	bmh_pool_prewarm(e && atoi(e) > 0 ? 2 * atoi(e) : 16); /* every host thread holds a context while it is inside a driver call */
 	return 0;
 }
 /* A run shorter than the pre-warming (a few hundred reads) must not reach the runtime's teardown with that thread still
@@ -71,6 +71,7 @@ __attribute__((constructor)) static void qa_shim_loaded(void)
 	 * kernel that happens to share its queue (measured: phase 1 of a 400 k-read chunk 0.48 s -> 0.21 s with 8 queues).
 	 * Must be in the environment before the runtime initialises; a value the user has set is left alone. */
 	setenv("GPU_MAX_HW_QUEUES", "8", 0);
+	bmh_set_device_gate(gpu_enter, gpu_leave); /* the library holds a GPU place for its device sections only */
 	if (e && e[0] == '0') return;
 	if (!pl || !strstr(pl, "libbwamem_hip_dropin")) return; /* only when preloaded into a host program, not when merely dlopen()ed */
 	{ /* ... and only into `<prog> mem ...`: index building, usage errors etc. never touch the GPU */
@@ -130,25 +131,20 @@ typedef struct {
 	bmh_smem_call_t *calls;
 	uint64_t *intv_off;
 	bmh_smem_intv_t *intv;
-	uint64_t *sa_k, *sa_pos; /* sorted keys and their positions */
+	uint64_t *sa_k, *sa_pos; /* per interval: where its run of positions starts (bmh_chain_sa_keys); the positions */
 	size_t n_sa;
 } qa_seed_t;
 static double g_seed_density[2] = {0.06, 0.35};
 static long long g_seed_us[3]; /* thread-microseconds: bmh_smem_batch, building the look-up keys, bmh_sa_batch */
 static __thread qa_seed_t *qa_seed; /* the batch this thread is chaining */
 
-static int cmp_u64(const void *a, const void *b)
-{
-	const uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
-	return x < y ? -1 : x > y;
-}
-
 static void qa_seed_batch_begin(bmh_ctx_t *ctx, const ref_mem_opt_t *opt, const ref_bwt_t *bwt, int n, const bmh_read_t *reads)
 {
 	bmh_bwt_t ib;
 	bmh_smem_opt_t so;
 	qa_seed_t *S;
-	size_t tot = 0, call_cap, intv_cap, nk = 0, k;
+	size_t tot = 0, call_cap, intv_cap, nk = 0;
+	uint64_t *keys = 0;
 	double ts[4];
 	int r, rc, i;
 	qa_seed = 0;
@@ -180,26 +176,19 @@ static void qa_seed_batch_begin(bmh_ctx_t *ctx, const ref_mem_opt_t *opt, const 
 		if (dc > g_seed_density[0]) g_seed_density[0] = dc;
 		if (di > g_seed_density[1]) g_seed_density[1] = di;
 	}
-	/* the suffix-array entries mem_insert_seed will ask for (bwamem.c:218-225): every occurrence of every interval that
-	 * is long and rare enough -- taken over ALL returned intervals, a superset of the merged list it walks */
-	for (k = 0; k < S->intv_off[n]; ++k) {
-		const bmh_smem_intv_t *p = &S->intv[k];
-		const int slen = (int)((uint32_t)p->info - (uint32_t)(p->info >> 32));
-		if (slen >= opt->min_seed_len && p->x[2] <= (uint64_t)opt->max_occ) nk += (size_t)p->x[2];
+	{ /* the suffix-array entries chaining will ask for, in interval order (bmh_chain_sa_keys), resolved by one GPU batch */
+		bmh_chain_opt_t co;
+		memset(&co, 0, sizeof(co));
+		co.min_seed_len = opt->min_seed_len, co.max_occ = opt->max_occ;
+		S->sa_k = (uint64_t *)malloc(8 * (S->intv_off[n] + 1)); /* here: sa_off, one entry per interval */
+		nk = (size_t)bmh_chain_sa_keys(&co, S->intv_off[n], S->intv, S->sa_k, 0);
+		keys = (uint64_t *)malloc(8 * (nk + 1)), S->sa_pos = (uint64_t *)malloc(8 * (nk + 1));
+		bmh_chain_sa_keys(&co, S->intv_off[n], S->intv, S->sa_k, keys);
+		S->n_sa = nk;
 	}
-	S->sa_k = (uint64_t *)malloc(8 * (nk + 1)), S->sa_pos = (uint64_t *)malloc(8 * (nk + 1));
-	for (k = 0, nk = 0; k < S->intv_off[n]; ++k) {
-		const bmh_smem_intv_t *p = &S->intv[k];
-		const int slen = (int)((uint32_t)p->info - (uint32_t)(p->info >> 32));
-		uint64_t j;
-		if (slen >= opt->min_seed_len && p->x[2] <= (uint64_t)opt->max_occ)
-			for (j = 0; j < p->x[2]; ++j) S->sa_k[nk++] = p->x[0] + j;
-	}
-	qsort(S->sa_k, nk, 8, cmp_u64);
-	for (k = 0, S->n_sa = 0; k < nk; ++k) /* unique */
-		if (S->n_sa == 0 || S->sa_k[S->n_sa - 1] != S->sa_k[k]) S->sa_k[S->n_sa++] = S->sa_k[k];
 	ts[2] = realtime();
-	if ((rc = bmh_sa_batch(ctx, S->sa_k, (int64_t)S->n_sa, S->sa_pos))) bmh_tls_die(bmh_last_error(ctx), rc);
+	if ((rc = bmh_sa_batch(ctx, keys, (int64_t)nk, S->sa_pos))) bmh_tls_die(bmh_last_error(ctx), rc);
+	free(keys);
 	ts[3] = realtime();
 	__sync_fetch_and_add(&g_seed_us[0], (long long)((ts[1] - ts[0]) * 1e6)), __sync_fetch_and_add(&g_seed_us[1], (long long)((ts[2] - ts[1]) * 1e6));
 	__sync_fetch_and_add(&g_seed_us[2], (long long)((ts[3] - ts[2]) * 1e6));
@@ -237,13 +226,10 @@ bmh_alnreg_v *mem_align1_core_batched(const ref_mem_opt_t *opt, const void *bwt,
 	p.o_del = opt->o_del, p.e_del = opt->e_del, p.o_ins = opt->o_ins, p.e_ins = opt->e_ins, p.zdrop = opt->zdrop;
 	p.a = opt->a, p.w = opt->w, p.pen_clip5 = opt->pen_clip5, p.pen_clip3 = opt->pen_clip3;
 	memcpy(p.mat, opt->mat, 25);
-	tq[0] = realtime();
-	gpu_enter(); /* contexts are taken inside the limited section, so no more of them exist than can be busy */
-	tq[1] = realtime();
+	tq[0] = tq[1] = realtime();
 	ctx = bmh_pool_get(&p);
 	qa_seed_batch_begin(ctx, opt, (const ref_bwt_t *)bwt, batch_size, reads); /* SMEMs + suffix-array look-ups of the batch on the GPU */
 	bmh_pool_put(ctx);
-	gpu_leave();
 	tq[2] = realtime();
 	{ /* chaining: mem_chain + mem_chain_flt (bwamem.c:1095-1097) over the batch's tables */
 		const qa_seed_t *S = qa_seed;
@@ -251,7 +237,7 @@ bmh_alnreg_v *mem_align1_core_batched(const ref_mem_opt_t *opt, const void *bwt,
 		co.w = opt->w, co.max_chain_gap = opt->max_chain_gap, co.min_seed_len = opt->min_seed_len, co.max_occ = opt->max_occ;
 		co.split_len = (int)(opt->min_seed_len * opt->split_factor + .499), co.split_width = opt->split_width;
 		co.mask_level = opt->mask_level, co.chain_drop_ratio = opt->chain_drop_ratio;
-		if ((rc = bmh_chain_reads(&co, bns->l_pac, batch_size, reads, S->call_off, S->calls, S->intv_off, S->intv, S->sa_k, S->sa_pos, S->n_sa, chn)))
+		if ((rc = bmh_chain_reads(&co, bns->l_pac, batch_size, reads, S->call_off, S->calls, S->intv_off, S->intv, S->sa_k, S->sa_pos, chn)))
 			bmh_tls_die("the batch's seeding tables do not cover its chaining", rc);
 		{
 			long long nc = 0;
@@ -261,7 +247,6 @@ bmh_alnreg_v *mem_align1_core_batched(const ref_mem_opt_t *opt, const void *bwt,
 	}
 	qa_seed_batch_end();
 	tq[3] = realtime();
-	gpu_enter();
 	tq[4] = realtime();
 	ctx = bmh_pool_get(&p);
 	{ /* reference resident in HBM, shared by all contexts: the kernels do bns_get_seq themselves.  BMH_PAC_RESIDENT=0
@@ -278,7 +263,6 @@ bmh_alnreg_v *mem_align1_core_batched(const ref_mem_opt_t *opt, const void *bwt,
 		__sync_fetch_and_add(&g_p1_cnt[3], st.short_sw);
 	}
 	bmh_pool_put(ctx);
-	gpu_leave();
 	tq[5] = realtime();
 	{ /* thread-seconds per stage, summed over the run (BMH_VERBOSE prints them per chunk) */
 		static const int a_[5] = {0, 1, 2, 3, 4};
@@ -382,7 +366,6 @@ static void qa_matesw_slice(void *data, int k, int tid)
 	int rc;
 	(void)tid;
 	if (hi <= lo) return;
-	gpu_enter();
 	ctx = qa_slice_ctx(J);
 	mo.pen_unpaired = J->opt->pen_unpaired, mo.max_matesw = J->opt->max_matesw, mo.min_seed_len = J->opt->min_seed_len, mo.rsv = 0;
 	if ((rc = bmh_matesw_batch(ctx, J->bns->l_pac, J->pac, hi - lo, J->reads + 2 * lo, J->regs + 2 * lo, J->pes, &mo, qa_dedup,
@@ -390,7 +373,6 @@ static void qa_matesw_slice(void *data, int k, int tid)
 		bmh_tls_die(bmh_last_error(ctx), rc);
 	bmh_driver_stats(ctx, &st);
 	bmh_pool_put(ctx);
-	gpu_leave();
 	__sync_fetch_and_add(&g_msw_calls, st.ext_tasks), __sync_fetch_and_add(&g_msw_bytes, st.pool_bytes);
 	if (st.rounds > g_msw_rounds_max) g_msw_rounds_max = st.rounds; /* (a benign race: statistics only) */
 }
@@ -407,15 +389,12 @@ static void qa_sam_slice(void *data, int k, int tid)
 	int rc, i;
 	(void)tid;
 	if (hi <= lo) return;
-	t0 = realtime();
-	gpu_enter();
-	t1 = realtime();
+	t0 = t1 = realtime();
 	ctx = qa_slice_ctx(J);
 	if ((rc = bmh_sam_batch(ctx, J->sopt, (const bmh_refidx_t *)J->bns, J->pac, J->pes, J->n_processed + lo, hi - lo, (bmh_seq_t *)(J->seqs + lo),
 	                        J->regs + lo, bwa_rg_id)))
 		bmh_tls_die(rc == BMH_E_ARG ? "a region could not be turned into an alignment (the reference aborts here too, bwamem.c:1183-1186)" : bmh_last_error(ctx), rc);
 	bmh_pool_put(ctx);
-	gpu_leave();
 	t2 = realtime();
 	for (i = lo; i < hi; ++i) free(J->regs[i].a);
 	__sync_fetch_and_add(&g_sam_us[0], (long long)((t1 - t0) * 1e6)), __sync_fetch_and_add(&g_sam_us[1], (long long)((t2 - t1) * 1e6));
@@ -432,7 +411,7 @@ void mem_process_seqs(const ref_mem_opt_t *opt, const void *bwt, const ref_bntse
 	bmh_sam_opt_t so;
 	bmh_read_t *reads;
 	qa_slice_job_t J;
-	double ctime, rtime, t_[4];
+	double ctime, rtime, t_[4], t_pes;
 	int i;
 	ctime = cputime(), rtime = realtime();
 	t_[0] = rtime;
@@ -450,6 +429,7 @@ void mem_process_seqs(const ref_mem_opt_t *opt, const void *bwt, const ref_bntse
 		if (pes0) memcpy(pes, pes0, 4 * sizeof(bmh_pestat_t));
 		else bmh_pestat(&so, bns->l_pac, n, w.regs, pes, bwa_verbose);
 	}
+	t_pes = realtime();
 	/* reads are base codes by now (bwamem.c:1093-1094) */
 	reads = (bmh_read_t *)malloc(sizeof(bmh_read_t) * (size_t)n);
 	for (i = 0; i < n; ++i) reads[i].l_seq = seqs[i].l_seq, reads[i].seq = (const uint8_t *)seqs[i].seq;
@@ -465,13 +445,8 @@ void mem_process_seqs(const ref_mem_opt_t *opt, const void *bwt, const ref_bntse
 	J.sopt = &so, J.n_processed = n_processed;
 	J.n_slices = opt->n_threads > 0 ? opt->n_threads : 1;
 	if (rescue) { /* the whole chunk's mate rescue (the block of mem_sam_pe at bwamem_pair.c:251-263), one bmh_matesw_batch per slice */
-		/* a slice holds its place on the GPU for all its rounds, and the rounds of a slice cost latency, not throughput:
-		 * more slices than places would only run one after the other (32 threads: 0.10 s against 0.04 s with 8 slices) */
-		const int all = J.n_slices;
 		g_msw_calls = g_msw_rounds_max = g_msw_bytes = 0;
-		J.n_slices = all < gpu_concurrency() ? all : gpu_concurrency();
 		kt_for(opt->n_threads, qa_matesw_slice, &J, J.n_slices);
-		J.n_slices = all;
 		if (getenv("BMH_VERBOSE"))
 			fprintf(stderr, "[bwamem_hip] mate rescue: %d pairs, %lld ksw_align2 calls in %lld GPU rounds, %lld pool bytes\n", n >> 1,
 			        g_msw_calls, g_msw_rounds_max, g_msw_bytes);
@@ -488,8 +463,8 @@ void mem_process_seqs(const ref_mem_opt_t *opt, const void *bwt, const ref_bntse
 		fprintf(stderr, "[bwamem_hip] phase 1 so far: %lld chains from bmh_chain_reads, %lld seeds extended (+%lld speculated in vain), %lld short-chain Smith-Watermans batched\n",
 		        g_p1_cnt[0], g_p1_cnt[1], g_p1_cnt[2], g_p1_cnt[3]);
 		fprintf(stderr, "[bwamem_hip] phase 2 thread-seconds so far: wait %.3f, bmh_sam_batch %.3f\n", g_sam_us[0] * 1e-6, g_sam_us[1] * 1e-6);
-		fprintf(stderr, "[bwamem_hip] chunk of %d reads: phase 1 %.3f s, pestat + mate rescue %.3f s, phase 2 (marking, pairing, global alignments, SAM) %.3f s\n", n,
-		        t_[1] - t_[0], t_[2] - t_[1], t_[3] - t_[2]);
+		fprintf(stderr, "[bwamem_hip] chunk of %d reads: phase 1 %.3f s, pestat %.3f s + mate rescue %.3f s, phase 2 (marking, pairing, global alignments, SAM) %.3f s\n", n,
+		        t_[1] - t_[0], t_pes - t_[1], t_[2] - t_pes, t_[3] - t_[2]);
 	}
 	free(w.regs);
 	if (bwa_verbose >= 3)

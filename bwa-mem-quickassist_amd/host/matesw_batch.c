@@ -11,7 +11,7 @@
  * invocation.  The first planned invocation of a pair is never speculative; the ones planned ahead may turn out to be
  * skipped (their ksw_align2 results are then simply not used) -- the outcome is exactly the reference's.
  *
- * Sequences: the pool holds every read once.  A reverse-complemented mate (:130-133) is BMH_F_QREV|BMH_F_QCOMP; with
+ * Sequences: the pool holds the reads of the pairs that need rescue, once each.  A reverse-complemented mate (:130-133) is BMH_F_QREV|BMH_F_QCOMP; with
  * the reference resident on the device the window bns_get_seq would return (:143) is a BMH_F_TPAC task, otherwise it
  * is decoded on the host into the round's pool.
  */
@@ -76,7 +76,8 @@ int bmh_matesw_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n_pa
 {
 	const bmh_params_t *P;
 	pair_t *ps = 0;
-	uint64_t *read_off = 0;
+	uint64_t *read_off = 0; /* pool offsets of the two reads of each ACTIVE pair */
+	int *act = 0, n_act = 0, q;
 	uint8_t *pool = 0;
 	bmh_sw_task_t *tasks = 0;
 	bmh_sw_result_t *res = 0;
@@ -89,20 +90,48 @@ int bmh_matesw_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n_pa
 	if (!(P = bmh_ctx_params_(ctx))) return BMH_E_ARG;
 	if (n_pairs == 0) return BMH_OK;
 	tpac = bmh_ctx_has_pac_(ctx, pac, l_pac);
-	ps = (pair_t *)calloc((size_t)n_pairs, sizeof(pair_t));
-	read_off = (uint64_t *)malloc(sizeof(uint64_t) * 2 * (size_t)n_pairs);
-	if (!ps || !read_off) { rc = BMH_E_NOMEM; goto done; }
-	for (p = 0; p < 2 * n_pairs; ++p) {
-		if (reads[p].l_seq < 1 || reads[p].l_seq > 65535) { rc = BMH_E_RANGE; goto done; }
-		read_off[p] = reads_bytes, reads_bytes += (size_t)reads[p].l_seq;
+	/* Most pairs need no rescue at all: every candidate hit already has a properly placed mate, so each of its
+	 * mem_matesw calls returns at bwamem_pair.c:122 and nothing ever changes.  Whether that is so can be read off the
+	 * vectors as phase 1 left them (the first call that does NOT return there is the first that could change anything),
+	 * so only the other pairs -- a few per cent -- get a machine, copies of their candidate hits, and room in the pool. */
+	act = (int *)malloc(sizeof(int) * (size_t)n_pairs);
+	if (!act) { rc = BMH_E_NOMEM; goto done; }
+	for (p = 0; p < n_pairs; ++p) {
+		int i, busy = 0;
+		for (i = 0; i < 2 && !busy; ++i) {
+			const bmh_alnreg_v *a = &regs[2 * p + i], *ma = &regs[2 * p + !i];
+			size_t j, k;
+			int nb = 0;
+			for (j = 0; j < a->n && !busy; ++j) { /* the hits copied to b[i] (:252-257), the first max_matesw of them (:258-259) */
+				int skip[4];
+				if (a->a[j].score < a->a[0].score - o->pen_unpaired) continue;
+				if (nb++ >= o->max_matesw) break;
+				for (r = 0; r < 4; ++r) skip[r] = pes[r].failed ? 1 : 0;
+				for (k = 0; k < ma->n; ++k) {
+					int64_t dist;
+					r = infer_dir(l_pac, a->a[j].rb, ma->a[k].rb, &dist);
+					if (dist >= pes[r].low && dist <= pes[r].high) skip[r] = 1;
+				}
+				if (skip[0] + skip[1] + skip[2] + skip[3] != 4) busy = 1;
+			}
+		}
+		if (busy) act[n_act++] = p;
 	}
-	for (p = 0; p < n_pairs; ++p) { /* bwamem_pair.c:252-257 */
+	if (n_sw) memset(n_sw, 0, sizeof(int) * (size_t)n_pairs);
+	if (n_act == 0) goto done;
+	ps = (pair_t *)calloc((size_t)n_act, sizeof(pair_t));
+	read_off = (uint64_t *)malloc(sizeof(uint64_t) * 2 * (size_t)n_act);
+	if (!ps || !read_off) { rc = BMH_E_NOMEM; goto done; }
+	for (q = 0; q < n_act; ++q) {
 		int i;
 		size_t j;
+		p = act[q];
 		for (i = 0; i < 2; ++i) {
 			const bmh_alnreg_v *a = &regs[2 * p + i];
-			for (j = 0; j < a->n; ++j)
-				if (a->a[j].score >= a->a[0].score - o->pen_unpaired) push_reg(&ps[p].b[i], &a->a[j]);
+			if (reads[2 * p + i].l_seq < 1 || reads[2 * p + i].l_seq > 65535) { rc = BMH_E_RANGE; goto done; }
+			read_off[2 * q + i] = reads_bytes, reads_bytes += (size_t)reads[2 * p + i].l_seq;
+			for (j = 0; j < a->n; ++j) /* bwamem_pair.c:252-257 */
+				if (a->a[j].score >= a->a[0].score - o->pen_unpaired) push_reg(&ps[q].b[i], &a->a[j]);
 		}
 	}
 
@@ -115,9 +144,10 @@ int bmh_matesw_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n_pa
 		 * its inputs (hit, orientation, mate) do not depend on that state, so a result computed ahead is THE result; the
 		 * fold below re-derives skip[] and only uses what it then really needs.  Without this, a pair with h candidate
 		 * hits would cost h GPU round trips. */
-		for (p = 0; p < n_pairs; ++p) {
-			pair_t *s = &ps[p];
+		for (q = 0; q < n_act; ++q) {
+			pair_t *s = &ps[q];
 			int ii, jj;
+			p = act[q];
 			if (s->done) continue;
 			s->n_inv = 0;
 			for (ii = s->i, jj = s->j; ii < 2 && s->n_inv < LOOKAHEAD;) {
@@ -184,15 +214,19 @@ int bmh_matesw_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n_pa
 				first_round = 1;
 			}
 			if (first_round)
-				for (p = 0; p < 2 * n_pairs; ++p) memcpy(pool + read_off[p], reads[p].seq, (size_t)reads[p].l_seq);
+				for (q = 0; q < n_act; ++q) {
+					memcpy(pool + read_off[2 * q], reads[2 * act[q]].seq, (size_t)reads[2 * act[q]].l_seq);
+					memcpy(pool + read_off[2 * q + 1], reads[2 * act[q] + 1].seq, (size_t)reads[2 * act[q] + 1].l_seq);
+				}
 		}
-		for (p = 0; p < n_pairs; ++p) {
-			pair_t *s = &ps[p];
+		for (q = 0; q < n_act; ++q) {
+			pair_t *s = &ps[q];
 			int v;
+			p = act[q];
 			if (s->done) continue;
 			for (v = 0; v < s->n_inv; ++v) {
 				inv_t *e = &s->inv[v];
-				const int mate = 2 * p + !e->i, l_ms = reads[mate].l_seq;
+				const int mate = 2 * q + !e->i, l_ms = reads[2 * p + !e->i].l_seq; /* `mate` indexes read_off */
 				for (r = 0; r < 4; ++r) {
 					bmh_sw_task_t *t;
 					const int is_rev = (r >> 1 != (r & 1));
@@ -225,8 +259,9 @@ int bmh_matesw_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n_pa
 		}
 
 		/* ---- fold, invocation by invocation in the reference's order (:109-175), as far as the planned results reach */
-		for (p = 0; p < n_pairs; ++p) {
-			pair_t *s = &ps[p];
+		for (q = 0; q < n_act; ++q) {
+			pair_t *s = &ps[q];
+			p = act[q];
 			if (s->done) continue;
 			for (;;) {
 				const bmh_alnreg_t *a;
@@ -283,11 +318,11 @@ int bmh_matesw_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n_pa
 		}
 	}
 	if (n_sw)
-		for (p = 0; p < n_pairs; ++p) n_sw[p] = ps[p].n;
+		for (q = 0; q < n_act; ++q) n_sw[act[q]] = ps[q].n;
 done:
 	bmh_ctx_set_driver_stats_(ctx, &st);
 	if (ps)
-		for (p = 0; p < n_pairs; ++p) free(ps[p].b[0].a), free(ps[p].b[1].a);
-	free(ps), free(read_off), free(pool), free(tasks), free(res);
+		for (q = 0; q < n_act; ++q) free(ps[q].b[0].a), free(ps[q].b[1].a);
+	free(ps), free(read_off), free(pool), free(tasks), free(res), free(act);
 	return rc;
 }

@@ -24,8 +24,17 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <time.h>
+
 #include "../../include/bwamem_hip.h"
 #include "sort_exact.h"
+
+static double now_s(void)
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 #define MIN_RATIO 0.8 /* bwamem_pair.c:14-18 */
 #define MIN_DIR_CNT 10
@@ -64,6 +73,22 @@ static int lt_score_hash(const void *x, const void *y)
 	return a->score > b->score || (a->score == b->score && a->hash < b->hash);
 }
 static int lt_u64(const void *x, const void *y) { return *(const uint64_t *)x < *(const uint64_t *)y; }
+static void sort_u64(uint64_t *a, size_t n, uint64_t max) /* insert sizes: 1..max_ins -> a counting sort where that is small */
+{
+	if (max < (1u << 22) && n > 64) {
+		uint32_t *cnt = (uint32_t *)calloc((size_t)max + 2, sizeof(uint32_t));
+		size_t i, k = 0;
+		uint64_t v;
+		if (cnt) {
+			for (i = 0; i < n; ++i) ++cnt[a[i] <= max ? a[i] : max + 1];
+			for (v = 0; v <= max + 1; ++v)
+				for (; cnt[v]; --cnt[v]) a[k++] = v;
+			free(cnt);
+			return;
+		}
+	}
+	bmh_sort_exact(a, n, 8, lt_u64);
+}
 typedef struct { uint64_t x, y; } pair64_t;
 static int lt_pair64(const void *p, const void *q)
 {
@@ -241,7 +266,7 @@ void bmh_pestat(const bmh_sam_opt_t *o, int64_t l_pac, int n, const bmh_alnreg_v
 			r->failed = 1;
 			continue;
 		} else if (verbose >= 0) fprintf(stderr, "[M::mem_pestat] analyzing insert size distribution for orientation %c%c...\n", "FR"[d >> 1 & 1], "FR"[d & 1]);
-		bmh_sort_exact(q, qn, 8, lt_u64);
+		sort_u64(q, qn, (uint64_t)o->max_ins); /* ks_introsort_64 (:75): equal keys are indistinguishable, any sort gives its array */
 		p25 = (int)q[(int)(.25 * qn + .499)];
 		p50 = (int)q[(int)(.50 * qn + .499)];
 		p75 = (int)q[(int)(.75 * qn + .499)];
@@ -587,6 +612,8 @@ int bmh_sam_batch(bmh_ctx_t *ctx, const bmh_sam_opt_t *o, const bmh_refidx_t *bn
 	str_t str = {0, 0, 0};
 	size_t j, cw = 8, mb = 16, n_fix = 0, arena_words = 0;
 	int i, rc = BMH_OK;
+	const int trace = getenv("BMH_DRIVER_TRACE") != 0;
+	double tt[4] = {0, 0, 0, 0};
 
 	if (!ctx || !o || !bns || !pac || n < 0 || (n > 0 && (!seqs || !regs)) || (pe && ((n & 1) || !pes))) return BMH_E_ARG;
 	if (n == 0) return BMH_OK;
@@ -596,6 +623,7 @@ int bmh_sam_batch(bmh_ctx_t *ctx, const bmh_sam_opt_t *o, const bmh_refidx_t *bn
 	if (!first || !reads || (pe && !pd)) { rc = BMH_E_NOMEM; goto done; }
 	for (i = 0; i < n; ++i) reads[i].l_seq = seqs[i].l_seq, reads[i].seq = (const uint8_t *)seqs[i].seq;
 
+	if (trace) tt[0] = now_s();
 	/* ---- pass A: decisions */
 	if (!pe) {
 		for (i = 0; i < n; ++i) { /* worker2's SE branch, bwamem.c:1285-1289 */
@@ -662,6 +690,7 @@ int bmh_sam_batch(bmh_ctx_t *ctx, const bmh_sam_opt_t *o, const bmh_refidx_t *bn
 	}
 	first[n] = W.n;
 
+	if (trace) tt[1] = now_s();
 	/* ---- pass B: bwa_fix_xref2 (bwa.c:179-222), then the alignments */
 	for (j = 0; j < W.n; ++j) {
 		want_t *x = &W.a[j];
@@ -739,6 +768,7 @@ int bmh_sam_batch(bmh_ctx_t *ctx, const bmh_sam_opt_t *o, const bmh_refidx_t *bn
 		for (j = 0; j < W.n; ++j) arena_words += (size_t)res[j].n_cigar + 2;
 	}
 
+	if (trace) tt[2] = now_s();
 	/* ---- pass C: mem_reg2aln's second half (bwamem.c:1203-1235) for every wanted region, then the text */
 	alns = (aln_t *)malloc(sizeof(aln_t) * (W.n + 2));
 	arena = (uint32_t *)malloc(4 * (arena_words + 4));
@@ -842,6 +872,9 @@ int bmh_sam_batch(bmh_ctx_t *ctx, const bmh_sam_opt_t *o, const bmh_refidx_t *bn
 			memcpy(seqs[rd].sam, str.s, str.l + 1);
 		}
 	}
+	if (trace)
+		fprintf(stderr, "[bwamem_hip] bmh_sam_batch %d reads, %zu alignments: marking + pairing %.1f ms, global alignments (bmh_reg2cigar_batch) %.1f ms, coordinates + text %.1f ms\n",
+		        n, W.n, (tt[1] - tt[0]) * 1e3, (tt[2] - tt[1]) * 1e3, (now_s() - tt[2]) * 1e3);
 done:
 	free(W.a), free(pd), free(reads), free(reqs), free(res), free(cig), free(md), free(first), free(alns), free(arena), free(pv.a), free(pu.a),
 	    free(str.s);

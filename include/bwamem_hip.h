@@ -128,6 +128,14 @@ int bmh_ctx_sync(bmh_ctx_t *ctx); /* waits for the stream; returns a pending BMH
  * the longest query the launch must handle (default 512).  Longer tasks fail with BMH_E_RANGE. */
 int bmh_ctx_set_qcap(bmh_ctx_t *ctx, int max_qlen);
 
+/* A process-wide gate around the DEVICE SECTIONS of the host-buffer entry points below (upload, kernels, download):
+ * enter() is called before the first device operation of a call and leave() after its last.  A program that drives the
+ * library from many host threads -- the reference runs phase 1 and 2 on n_threads pthreads -- can bound how many of
+ * them are inside device sections at once (more only queue up behind one another on the GPU), while the host work of
+ * the L3 drivers around those sections (state machines, band logic, text) runs on all threads.  NULL, NULL removes it. */
+typedef void (*bmh_gate_fn)(void);
+int bmh_set_device_gate(bmh_gate_fn enter, bmh_gate_fn leave);
+
 /* ---- L2, host buffers: H2D copy, launch, D2H copy, synchronous on return. */
 int bmh_extend_batch(bmh_ctx_t *ctx, const uint8_t *seqpool, size_t pool_bytes,
                      const bmh_ext_task_t *tasks, int64_t n, bmh_ext_result_t *results);
@@ -504,19 +512,23 @@ int bmh_sa_batch(bmh_ctx_t *ctx, const uint64_t *k, int64_t n, uint64_t *pos);
  * Replaces: mem_chain (reference bwamem.c:283-306) = smem_next2's rounds (:118-157) + mem_insert_seed (:208-243, over
  *           test_and_merge :186-206 and klib's B-tree of chains) + the in-order read-out, followed by mem_chain_flt
  *           (:319-380) -- lines bwamem.c:1096-1097 of mem_align1_core_batched.
- * call_off / calls / intv_off / intv are bmh_smem_batch's outputs for the same reads.  sa_k (ascending, unique) and
- * sa_pos are a table of bwt_sa results that covers every occurrence x[0]..x[0]+x[2]-1 of every interval with length
- * >= min_seed_len and x[2] <= max_occ (BMH_E_ARG if an entry is missing).  chains[r] is filled like mem_chain's return
- * value: a malloc'd array of chains in the reference's order, each with a malloc'd seed array; the caller frees both. */
+ * call_off / calls / intv_off / intv are bmh_smem_batch's outputs for the same reads.  The bwt_sa results come in
+ * interval order: bmh_chain_sa_keys lists, for every interval that is long and rare enough (length >= min_seed_len,
+ * x[2] <= max_occ), its suffix-array indices x[0]..x[0]+x[2]-1 and records in sa_off[k] where interval k's run starts
+ * (UINT64_MAX = never looked up); the caller resolves the list with ONE bmh_sa_batch and passes the positions as sa_pos
+ * -- no sorting, no searching.  chains[r] is filled like mem_chain's return value: a malloc'd array of chains in the
+ * reference's order, each with a malloc'd seed array; the caller frees both. */
 typedef struct bmh_chain_opt { /* the mem_opt_t fields seeding + chaining read (bwamem.h:21-48) */
 	int32_t w, max_chain_gap, min_seed_len, max_occ;
 	int32_t split_len;   /* (int)(min_seed_len * split_factor + .499), bwamem.c:211 */
 	int32_t split_width;
 	float mask_level, chain_drop_ratio;
 } bmh_chain_opt_t;
+uint64_t bmh_chain_sa_keys(const bmh_chain_opt_t *o, uint64_t n_intv, const bmh_smem_intv_t *intv, uint64_t *sa_off /* [n_intv] */,
+                           uint64_t *keys /* NULL: count only */);
 int bmh_chain_reads(const bmh_chain_opt_t *o, int64_t l_pac, int n_reads, const bmh_read_t *reads, const uint32_t *call_off,
-                    const bmh_smem_call_t *calls, const uint64_t *intv_off, const bmh_smem_intv_t *intv, const uint64_t *sa_k,
-                    const uint64_t *sa_pos, size_t n_sa, bmh_chain_v *chains);
+                    const bmh_smem_call_t *calls, const uint64_t *intv_off, const bmh_smem_intv_t *intv, const uint64_t *sa_off,
+                    const uint64_t *sa_pos, bmh_chain_v *chains);
 
 #ifdef __cplusplus
 }

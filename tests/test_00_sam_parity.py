@@ -215,3 +215,19 @@ def test_pe_sam_identical_with_a_device_list(genome):
     ref_sam = _run(fa, [fq1, fq2], os.path.join(tmp, "ref_dl.sam"), extra, False)
     dut_sam = _run(fa, [fq1, fq2], os.path.join(tmp, "dut_dl.sam"), extra, True, {"BMH_DEVICES": "0,0"})
     assert len(ref_sam) >= 1200 and ref_sam == dut_sam
+
+
+def test_pe_sam_identical_over_all_visible_devices(genome):
+    """$BMH_DEVICES naming EVERY visible GPU (one on this pool, eight on a node): the shim's contexts land on all of them in
+    turn, each device holds its own resident reference and index, no exchange between them -- and the SAM is the reference's."""
+    import torch
+    ndev = torch.cuda.device_count()
+    rng, tmp, fa, ref = genome
+    r1, r2 = _sim_reads(rng, ref, 900, 150, False, pair=True, rescue=0.3)
+    fq1, fq2 = os.path.join(tmp, "ad_1.fq"), os.path.join(tmp, "ad_2.fq")
+    reflib.write_fastq(fq1, r1, "p")
+    reflib.write_fastq(fq2, r2, "p")
+    extra = ["-t", str(max(4, 2 * ndev)), "-b", "128"]
+    ref_sam = _run(fa, [fq1, fq2], os.path.join(tmp, "ref_ad.sam"), extra, False)
+    dut_sam = _run(fa, [fq1, fq2], os.path.join(tmp, "dut_ad.sam"), extra, True, {"BMH_DEVICES": ",".join(str(d) for d in range(ndev))})
+    assert len(ref_sam) >= 1800 and ref_sam == dut_sam

@@ -56,7 +56,7 @@ def test_bench_prints_one_contract_line_on_the_metric_config():
     pb = d["cpu_baseline_pipeline"]
     if "skipped" not in pb:  # needs oracle/_ref (travels with the tree)
         assert pb["kind"] == "reference" and pb["value"] > 0 and pb["dut_value"] > 0 and pb["sam_identical"] is True
-        assert pb["dut_detail"]["cigar_table"]["to_host"] == 0
+        assert pb["dut_detail"]["chunks"] and "phase 2 (marking, pairing, global alignments, SAM)" in pb["dut_detail"]["chunks"][0]
 
 
 def test_bench_round1_line_still_runs():

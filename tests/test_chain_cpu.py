@@ -39,10 +39,21 @@ def run_chain_reads(lib, o, l_pac, reads, calls, intvs, sa_k, sa_pos):
     fc = np.ascontiguousarray(np.concatenate(calls)) if n else np.zeros(0, kswlib.SMEM_CALL)
     fi = np.ascontiguousarray(np.concatenate(intvs)) if n else np.zeros(0, kswlib.SMEM_INTV)
     out = (_ChainV * n)()
+    # the suffix-array positions in interval order, as the library's own key list asks for them (one bmh_sa_batch on the
+    # GPU in production; here they come out of the fixture's sorted table)
+    lib.bmh_chain_sa_keys.restype = C.c_uint64
+    sa_off = np.zeros(len(fi) + 1, dtype=np.uint64)
+    nk = lib.bmh_chain_sa_keys(o.ctypes.data_as(C.c_void_p), C.c_uint64(len(fi)), fi.ctypes.data_as(C.c_void_p), sa_off.ctypes.data_as(C.c_void_p), None)
+    keys = np.zeros(nk + 1, dtype=np.uint64)
+    assert lib.bmh_chain_sa_keys(o.ctypes.data_as(C.c_void_p), C.c_uint64(len(fi)), fi.ctypes.data_as(C.c_void_p), sa_off.ctypes.data_as(C.c_void_p),
+                                 keys.ctypes.data_as(C.c_void_p)) == nk
+    at = np.searchsorted(sa_k, keys[:nk])
+    assert (sa_k[at] == keys[:nk]).all()
+    pos = np.ascontiguousarray(np.concatenate([sa_pos[at], np.zeros(1, np.uint64)]))
     rc = lib.bmh_chain_reads(o.ctypes.data_as(C.c_void_p), C.c_int64(l_pac), C.c_int(n), C.cast(c_reads, C.c_void_p),
                              call_off.ctypes.data_as(C.c_void_p), fc.ctypes.data_as(C.c_void_p), intv_off.ctypes.data_as(C.c_void_p),
-                             fi.ctypes.data_as(C.c_void_p), sa_k.ctypes.data_as(C.c_void_p), sa_pos.ctypes.data_as(C.c_void_p),
-                             C.c_size_t(len(sa_k)), C.cast(out, C.c_void_p))
+                             fi.ctypes.data_as(C.c_void_p), sa_off.ctypes.data_as(C.c_void_p), pos.ctypes.data_as(C.c_void_p),
+                             C.cast(out, C.c_void_p))
     assert rc == 0, rc
     res = []
     for k in range(n):

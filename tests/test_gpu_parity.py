@@ -120,6 +120,19 @@ def test_global_realistic(ctx):
     _cmp_glb(ctx, kswlib.make_params(), pool, tasks, words)
 
 
+def test_global_band_wider_than_the_query_alone_in_a_batch(ctx):
+    """A task whose band (32..63) is wider than its query is short: the host's sizing looks at min(w, qlen), the device bins on w
+    as given -- the 128-slot kernel must be launched for it even when nothing else in the batch lifts the batch's band."""
+    rng = np.random.default_rng(2081)
+    for w, ql, tl in ((40, 20, 22), (63, 9, 12), (33, 31, 28)):
+        q = rng.integers(0, 4, ql, dtype=np.uint8)
+        t = np.concatenate([q[: ql // 2], rng.integers(0, 4, tl - ql // 2, dtype=np.uint8)])[:tl]
+        pool = np.concatenate([q, t, np.zeros(16, np.uint8)])
+        tasks = np.zeros(1, dtype=kswlib.GLB_TASK)
+        tasks[0] = (0, ql, ql, tl, w, 0, ql + tl + 2)
+        _cmp_glb(ctx, kswlib.make_params(), pool, tasks, ql + tl + 2)
+
+
 def test_global_long_hbm_scratch(ctx):
     """Direction matrix too large for LDS -> HBM scratch slab variant of the kernel."""
     rng = np.random.default_rng(208)

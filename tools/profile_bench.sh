@@ -7,7 +7,8 @@ shift || true
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="bench.py --steps 5 --warmup 1 --no-cpu-baseline $*"
+# the baselines start child processes and burn CPU: they are not what is profiled
+ARGS="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-pipeline-baseline $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $ARGS > $OUT/trace.log 2>&1
 # PMC passes (each in its own run; no tracing domains beside kernel-trace)
 i=0

@@ -49,4 +49,6 @@ for k in sorted(acc):
                       "FETCH_SIZE_KiB": means["FETCH_SIZE"], "WRITE_SIZE_KiB": means["WRITE_SIZE"]}
     print()
 if tj:
-    json.dump({"source": os.path.basename(d), "kernels": traffic}, open(tj, "w"), indent=1)
+    commit = os.popen("git -C %s rev-parse --short HEAD 2>/dev/null" % os.path.dirname(os.path.abspath(__file__))).read().strip()
+    json.dump({"source": os.path.basename(d), "commit": commit or "unknown (no git on the GPU box: see the profile's file name)", "kernels": traffic},
+              open(tj, "w"), indent=1)
