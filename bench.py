@@ -168,6 +168,7 @@ def main():
     ap.add_argument("--global-per-read", type=float, default=0.85, help="ksw_global2 tasks per read (measured, SURVEY.md §8a2)")
     ap.add_argument("--rescue-rate", type=float, default=0.06, help="ksw_align2 mate-rescue tasks per pair (measured 0.02-0.11)")
     ap.add_argument("--rescue-batch", type=int, default=1_000_000, help="mate-rescue tasks are collected over chunks into batches of up to this many")
+    ap.add_argument("--ext-contexts", type=int, default=1, help="with --streams 3: alternate the chunks' extension stage over this many contexts/streams")
     ap.add_argument("--streams", type=int, default=3, choices=[1, 3],
                     help="3: one context and HIP stream per stage, so chunk k's global alignments run beside chunk k+1's extensions "
                          "(measured +10 %% reads/s); 1: the stages back to back on one stream (every kernel alone on the chip)")
@@ -267,16 +268,21 @@ def main():
 
     stream = torch.cuda.Stream(dev)
     assert stream.cuda_stream != 0
-    ctxs = [pkg.Context(local_rank, params) for _ in range(3 if args.streams == 3 else 1)]
+    n_ext = max(1, args.ext_contexts) if args.streams == 3 else 1
+    ctxs = [pkg.Context(local_rank, params) for _ in range((2 + n_ext) if args.streams == 3 else 1)]
     streams = [stream] + [torch.cuda.Stream(dev) for _ in ctxs[1:]]
     for c, s in zip(ctxs, streams):
         c.set_qcap(max(qmax, gqmax))
         c.set_stream(s.cuda_stream)
-    cx_ext, cx_glb, cx_sw = ctxs[0], ctxs[1 % len(ctxs)], ctxs[2 % len(ctxs)]
+    cx_exts, cx_glb, cx_sw = ([ctxs[0]] + ctxs[3:]) if args.streams == 3 else [ctxs[0]], ctxs[1 % len(ctxs)], ctxs[2 % len(ctxs)]
+    ext_streams = ([streams[0]] + streams[3:]) if args.streams == 3 else [streams[0]]
+    for k, c in enumerate(chunks):
+        c["k"] = k
+    cx_ext = cx_exts[0]
     torch.cuda.synchronize(dev)
 
     def run_chunk(c, cig):
-        cx_ext.seedext_batch_device(c["pool"].data_ptr(), c["seeds"].data_ptr(), c["n"], c["sres"].data_ptr())
+        cx_exts[c["k"] % len(cx_exts)].seedext_batch_device(c["pool"].data_ptr(), c["seeds"].data_ptr(), c["n"], c["sres"].data_ptr())
         cx_glb.global_batch_device(c["gpool"].data_ptr(), c["gtasks"].data_ptr(), c["ng"], c["gres"].data_ptr(), cig.data_ptr())
 
     def run_sw(b):

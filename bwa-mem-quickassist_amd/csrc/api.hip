@@ -26,8 +26,10 @@ int set_hip_error(bmh_ctx *ctx, hipError_t e, const char *what)
 int ensure(bmh_ctx *ctx, DevBuf &b, size_t bytes)
 {
 	if (bytes <= b.cap) return BMH_OK;
-	size_t cap = std::max(bytes, b.cap + b.cap / 2);
-	cap = (cap + 255) & ~(size_t)255;
+	// growing means hipFree + hipMalloc, and both synchronise the whole device -- with many host threads in flight a
+	// workspace that creeps up by a few per cent per batch stalls everybody again and again.  So: generous steps.
+	size_t cap = std::max(bytes + bytes / 4, b.cap * 2);
+	cap = (cap + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
 	if (b.p) BMH_HIP(ctx, hipFree(b.p));
 	b.p = nullptr, b.cap = 0;
 	hipError_t e = hipMalloc(&b.p, cap);
@@ -42,8 +44,8 @@ int ensure(bmh_ctx *ctx, DevBuf &b, size_t bytes)
 int ensure_host(bmh_ctx *ctx, DevBuf &b, size_t bytes)
 {
 	if (bytes <= b.cap) return BMH_OK;
-	size_t cap = std::max(bytes, b.cap * 2);
-	cap = (cap + 4095) & ~(size_t)4095;
+	size_t cap = std::max(bytes + bytes / 4, b.cap * 2); // pinned allocations are slow and synchronise too: see ensure()
+	cap = (cap + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
 	if (b.p) BMH_HIP(ctx, hipHostFree(b.p));
 	b.p = nullptr, b.cap = 0;
 	hipError_t e = hipHostMalloc(&b.p, cap, hipHostMallocDefault);
@@ -821,6 +823,19 @@ int bmh_ctx_reserve_staging(bmh_ctx_t *ctx, size_t upload_bytes, size_t download
 	int rc;
 	BMH_HIP(ctx, hipSetDevice(ctx->device));
 	if ((rc = ensure_host(ctx, ctx->h_up, upload_bytes)) || (rc = ensure_host(ctx, ctx->h_down, download_bytes))) return rc;
+	return BMH_OK;
+}
+
+int bmh_ctx_reserve_device(bmh_ctx_t *ctx, size_t pool_bytes, int64_t max_tasks, size_t cigar_words)
+{
+	if (!ctx || max_tasks < 0) return BMH_E_ARG;
+	int rc;
+	const size_t N = (size_t)max_tasks;
+	BMH_HIP(ctx, hipSetDevice(ctx->device));
+	if ((rc = ensure(ctx, ctx->d_pool, pool_bytes + 16)) || (rc = ensure(ctx, ctx->d_tasks, N * 40 + 64)) || (rc = ensure(ctx, ctx->d_res, N * 32 + 64)) ||
+	    (rc = ensure(ctx, ctx->d_cigar, (cigar_words + 4) * 4)) ||
+	    (rc = ensure(ctx, ctx->d_bins, (16 + (size_t)kSortBins * kSortKeysHost + (N + 1) / 2 + 1 + (size_t)kSortBins * N) * 4)))
+		return rc;
 	return BMH_OK;
 }
 

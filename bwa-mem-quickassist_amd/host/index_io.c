@@ -7,6 +7,8 @@
  *                 (bwt_restore_sa, bwt.c:380-401)
  *   <prefix>.ann  "l_pac n_seqs seed", then per sequence "gi name [comment]" and "offset len n_ambs"
  *                 (bns_restore_core, bntseq.c:94-140)
+ *   <prefix>.amb  "l_pac n_seqs n_holes", then per run of ambiguous bases "offset len letter" (bntseq.c:136-150); the
+ *                 2-bit reference holds a random base there
  *   <prefix>.pac  l_pac/4+1 bytes of 2-bit codes, four per byte, first base in the top bits (bwa.c:291-292)
  */
 #include <stdio.h>
@@ -43,7 +45,7 @@ void bmh_index_free(bmh_index_t *ix)
 	free((void *)ix->bwt.bwt), free((void *)ix->bwt.sa), free(ix->pac);
 	for (i = 0; i < ix->n_seqs; ++i)
 		if (ix->names) free(ix->names[i]);
-	free(ix->names), free(ix->offsets), free(ix->lens), free(ix);
+	free(ix->names), free(ix->offsets), free(ix->lens), free(ix->hole_offsets), free(ix->hole_lens), free(ix->hole_chars), free(ix);
 }
 
 int bmh_index_load(const char *prefix, bmh_index_t **out)
@@ -94,6 +96,21 @@ int bmh_index_load(const char *prefix, bmh_index_t **out)
 			if (!fgets(line, sizeof(line), f)) goto fail; /* the rest of the line is the optional comment */
 			if (fscanf(f, "%lld%d%d", &off, &len, &n_ambs) != 3) goto fail;
 			ix->names[i] = strdup(name), ix->offsets[i] = off, ix->lens[i] = len;
+		}
+	}
+	fclose(f);
+
+	if (!(f = open_ext(prefix, ".amb", "r"))) goto fail;
+	{
+		long long l_pac, off;
+		int n_seqs, len;
+		char letter[64];
+		if (fscanf(f, "%lld%d%d", &l_pac, &n_seqs, &ix->n_holes) != 3 || l_pac != ix->l_pac || n_seqs != ix->n_seqs || ix->n_holes < 0) goto fail;
+		ix->hole_offsets = (int64_t *)calloc((size_t)ix->n_holes + 1, 8), ix->hole_lens = (int32_t *)calloc((size_t)ix->n_holes + 1, 4);
+		ix->hole_chars = (char *)calloc((size_t)ix->n_holes + 1, 1);
+		for (i = 0; i < ix->n_holes; ++i) {
+			if (fscanf(f, "%lld%d%63s", &off, &len, letter) != 3) goto fail;
+			ix->hole_offsets[i] = off, ix->hole_lens[i] = len, ix->hole_chars[i] = letter[0];
 		}
 	}
 	fclose(f);

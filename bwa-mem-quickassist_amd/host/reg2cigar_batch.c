@@ -10,9 +10,10 @@
  * and inside each try what bwa_gen_cigar2() does (bwa.c:89-172): fetch [rb,re) from the 2-bit
  * reference, reverse query and reference when the hit is on the reverse strand (so indels are
  * left-aligned), pick the band (bwa.c:116-125), run the banded global alignment, derive NM and MD.
- * The global alignments of all regions still in play form ONE bmh_global_batch() per try ("round"),
- * at most three rounds per batch; band choice, the no-gap shortcut (bwa.c:108-114), NM and MD are host
- * work.  Results are bit-identical to the per-region reference calls.
+ * bwa_gen_cigar2 is a pure function of (region, band): the global alignments of ALL the bands a region could be
+ * tried with form ONE bmh_global_batch() per call, and the loop is replayed over the results (round 1 ran one
+ * batch per try); band choice, the no-gap shortcut (bwa.c:108-114), NM and MD are host work.  Results are
+ * bit-identical to the per-region reference calls.
  */
 #include <stdio.h>
 #include <stdlib.h>
@@ -88,8 +89,9 @@ typedef struct {
 	uint64_t q_off, t_off; /* oriented copies in the pool */
 	int ql, tl, w2, last_sc, tries, active, rev, valid, nodp;
 	int score, n_cigar;
-	uint32_t slot;  /* cigar scratch slot of the current round */
-	uint32_t fslot; /* this region's fixed slot in the keeper array */
+	int64_t tidx[3];    /* the GPU task of each of the (up to) three tries, -1 = none */
+	int64_t final_task; /* ... and the one whose result the loop ends on */
+	const uint32_t *cig; /* the final try's CIGAR words (in one of the scratch arrays); NULL = the no-DP case, one M run */
 } cg_t;
 
 int bmh_reg2cigar_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, const bmh_read_t *reads, int64_t n_req,
@@ -101,10 +103,10 @@ int bmh_reg2cigar_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, const
 	uint8_t *pool = 0;
 	bmh_glb_task_t *tasks = 0;
 	bmh_glb_result_t *gres = 0;
-	uint32_t *scratch = 0, *final_cig = 0;
-	int64_t *owner = 0, k, n_active;
-	size_t pool_bytes = 0, scratch_words = 0, cig_used = 0, md_used = 0;
-	int rc = BMH_OK, round;
+	uint32_t *scratch = 0, *bigscr = 0; /* CIGAR words of the batch's tasks (24 slots each); of the few redone with full slots */
+	int64_t *owner = 0, k, task_cap = 0;
+	size_t pool_bytes = 0, cig_used = 0, md_used = 0;
+	int rc = BMH_OK;
 	const int trace = getenv("BMH_DRIVER_TRACE") != 0; /* where a call's time goes, on stderr */
 	double tt[4] = {0, 0, 0, 0}, t0 = 0;
 
@@ -129,16 +131,13 @@ int bmh_reg2cigar_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, const
 		c->ql = ql, c->tl = (int)tl, c->rev = r->rb >= l_pac;
 		c->q_off = pool_bytes, pool_bytes += (size_t)ql;
 		c->t_off = pool_bytes, pool_bytes += (size_t)tl;
-		c->fslot = (uint32_t)scratch_words;
-		scratch_words += (size_t)ql + (size_t)tl + 2;
 	}
 	pool = (uint8_t *)malloc(pool_bytes + 16);
-	tasks = (bmh_glb_task_t *)malloc(sizeof(*tasks) * (size_t)n_req);
-	gres = (bmh_glb_result_t *)malloc(sizeof(*gres) * (size_t)n_req);
+	task_cap = n_req + n_req / 4 + 64;
+	tasks = (bmh_glb_task_t *)malloc(sizeof(*tasks) * (size_t)task_cap);
+	gres = (bmh_glb_result_t *)malloc(sizeof(*gres) * (size_t)task_cap);
 	owner = (int64_t *)malloc(sizeof(int64_t) * (size_t)n_req);
-	scratch = (uint32_t *)malloc(4 * (scratch_words + 4));
-	final_cig = (uint32_t *)malloc(4 * (scratch_words + 4)); /* last try's CIGAR of every region, same slots */
-	if (!pool || !tasks || !gres || !owner || !scratch || !final_cig) { rc = BMH_E_NOMEM; goto done; }
+	if (!pool || !tasks || !gres || !owner) { rc = BMH_E_NOMEM; goto done; }
 
 	for (k = 0; k < n_req; ++k) { /* oriented copies (bwa.c:100-107) and the initial band (bwamem.c:1187-1191) */
 		const bmh_cigar_req_t *r = &reqs[k];
@@ -168,80 +167,109 @@ int bmh_reg2cigar_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, const
 	memset(pool + pool_bytes, 0, 16);
 	if (trace) tt[1] = now_s();
 
-	for (round = 0; round < 3; ++round) { /* bwamem.c:1194-1201, all regions in lock step */
+	/* ---- bwamem.c:1194-1201.  The loop tries up to three bands (w2, 2*w2, 4*w2) and stops when the score repeats or is
+	 * good enough.  bwa_gen_cigar2 is a pure function of (region, band), so all the bands a region COULD be tried with are
+	 * aligned in ONE GPU batch and the loop is then replayed over the results: one device round trip per call instead of
+	 * up to three (under eight host threads each costs ~10 ms whatever its size).  A try whose band equals an earlier
+	 * try's (the band saturates at bwa.c:119-124) shares its task. */
+	{
 		size_t slot = 0;
-		n_active = 0;
+		int64_t n_tasks = 0, n_big = 0;
 		for (k = 0; k < n_req; ++k) {
 			cg_t *c = &cg[k];
+			const int single = reqs[k].truesc == INT32_MIN;
+			int t_, prev_w = -1;
+			c->tidx[0] = c->tidx[1] = c->tidx[2] = -1;
 			if (!c->active) continue;
-			++c->tries;
-			c->slot = (uint32_t)slot, c->nodp = 0;
-			if (c->ql == c->tl && c->w2 == 0) { /* no gap, no DP: bwa.c:108-114 */
+			if (c->ql == c->tl && c->w2 == 0) { /* no gap, no DP: bwa.c:108-114 (0 << k stays 0) */
 				const uint8_t *q = pool + c->q_off, *t = pool + c->t_off;
 				int i, sc = 0;
 				for (i = 0; i < c->ql; ++i) sc += p->mat[t[i] * 5 + q[i]];
-				final_cig[c->fslot] = (uint32_t)c->ql << 4; /* straight into the keeper: the GPU call rewrites `scratch` */
-				c->score = sc, c->n_cigar = 1, c->nodp = 1;
-				slot += 1;
-			} else { /* band of this try, bwa.c:116-125 */
-				bmh_glb_task_t *t = &tasks[n_active];
+				c->nodp = 1, c->score = sc;
+				continue;
+			}
+			for (t_ = 0; t_ < (single ? 1 : 3); ++t_) { /* band of this try, bwa.c:116-125 */
+				const int w2 = c->w2 << t_;
 				const int max_ins = (int)((double)(((c->ql + 1) >> 1) * p->mat[0] - p->o_ins) / p->e_ins + 1.);
 				const int max_del = (int)((double)(((c->ql + 1) >> 1) * p->mat[0] - p->o_del) / p->e_del + 1.);
 				int max_gap = max_ins > max_del ? max_ins : max_del, w, min_w;
+				bmh_glb_task_t *t;
+				if (c->ql == c->tl && w2 == 0) break;
 				max_gap = max_gap > 1 ? max_gap : 1;
 				w = (max_gap + abs(c->tl - c->ql) + 1) >> 1;
-				w = w < c->w2 ? w : c->w2;
+				w = w < w2 ? w : w2;
 				min_w = abs(c->tl - c->ql) + 3;
 				w = w > min_w ? w : min_w;
+				if (w == prev_w) { c->tidx[t_] = c->tidx[t_ - 1]; continue; }
+				prev_w = w;
+				if (n_tasks == task_cap) {
+					task_cap = task_cap + task_cap / 2 + 1024;
+					tasks = (bmh_glb_task_t *)realloc(tasks, sizeof(*tasks) * (size_t)task_cap);
+					gres = (bmh_glb_result_t *)realloc(gres, sizeof(*gres) * (size_t)task_cap);
+					if (!tasks || !gres) { rc = BMH_E_NOMEM; goto done; }
+				}
+				t = &tasks[n_tasks];
 				t->q_off = c->q_off, t->t_off = c->t_off, t->qlen = (uint16_t)c->ql, t->tlen = (uint16_t)c->tl, t->w = w;
 				/* a CIGAR can have ql+tl+1 operations but almost never has more than a few: reserve SMALL_CAP slots, so that the
 				 * words coming back over PCIe are not 99 % padding, and redo the rare task that needs more (below) */
 				t->cigar_off = (uint32_t)slot, t->cigar_cap = (uint32_t)(c->ql + c->tl + 2 < SMALL_CAP ? c->ql + c->tl + 2 : SMALL_CAP);
 				slot += t->cigar_cap;
-				owner[n_active++] = k;
+				c->tidx[t_] = n_tasks++;
 			}
 		}
-		if (n_active > 0) {
-			int64_t n_big = 0;
+		if (!(scratch = (uint32_t *)malloc(4 * (slot + 8)))) { rc = BMH_E_NOMEM; goto done; }
+		if (n_tasks > 0) {
 			if (trace) t0 = now_s();
-			if (round == 0) { if ((rc = bmh_upload_pool(ctx, pool, pool_bytes + 16))) goto done; }
-			rc = bmh_global_batch(ctx, 0, 0, tasks, n_active, gres, scratch, slot + 4);
+			if ((rc = bmh_upload_pool(ctx, pool, pool_bytes + 16))) goto done;
+			rc = bmh_global_batch(ctx, 0, 0, tasks, n_tasks, gres, scratch, slot + 4);
 			if (trace) tt[2] += now_s() - t0;
 			if (rc && rc != BMH_E_CIGAR_CAP) goto done;
-			for (k = 0; k < n_active; ++k) {
-				cg_t *c = &cg[owner[k]];
-				c->score = gres[k].score, c->n_cigar = gres[k].n_cigar;
-				if ((uint32_t)c->n_cigar <= tasks[k].cigar_cap) memcpy(final_cig + c->fslot, scratch + c->slot, 4 * (size_t)c->n_cigar);
-				else tasks[n_big] = tasks[k], owner[n_big] = owner[k], ++n_big; /* (n_big <= k: in-place compaction) */
-			}
-			if (n_big > 0) { /* the few long CIGARs again, with the full ql+tl+2 slots */
-				slot = 0;
-				for (k = 0; k < n_big; ++k) {
-					cg_t *c = &cg[owner[k]];
-					tasks[k].cigar_off = (uint32_t)slot, tasks[k].cigar_cap = (uint32_t)(c->ql + c->tl + 2), c->slot = (uint32_t)slot;
-					slot += tasks[k].cigar_cap;
-				}
-				if ((rc = bmh_global_batch(ctx, 0, 0, tasks, n_big, gres, scratch, slot + 4))) goto done;
-				for (k = 0; k < n_big; ++k) {
-					cg_t *c = &cg[owner[k]];
-					c->score = gres[k].score, c->n_cigar = gres[k].n_cigar;
-					memcpy(final_cig + c->fslot, scratch + c->slot, 4 * (size_t)c->n_cigar);
-				}
-			}
 			rc = BMH_OK;
 		}
-		n_active = 0;
-		for (k = 0; k < n_req; ++k) { /* keep this try's CIGAR, decide about the next one */
+		for (k = 0; k < n_req; ++k) { /* replay the loop (bwamem.c:1194-1201) over the precomputed tries */
 			cg_t *c = &cg[k];
+			const int single = reqs[k].truesc == INT32_MIN;
+			int t_;
 			if (!c->active) continue;
-			if (c->score == c->last_sc) c->active = 0; /* bwamem.c:1198 */
-			else {
-				c->last_sc = c->score, c->w2 <<= 1;
-				if (reqs[k].truesc == INT32_MIN || !(c->tries < 3 && c->score < reqs[k].truesc - p->a)) c->active = 0; /* bwamem.c:1201 */
+			c->active = 0;
+			if (c->nodp) { /* the same score at every band: try 1, and try 2 if try 1 was not good enough (then score == last_sc) */
+				c->cig = 0; /* one match run of ql bases: written out at the end */
+				c->n_cigar = 1, c->tries = (!single && c->score < reqs[k].truesc - p->a) ? 2 : 1;
+				continue;
 			}
-			n_active += c->active;
+			for (t_ = 0;; ++t_) {
+				const int64_t ti = c->tidx[t_];
+				++c->tries;
+				c->score = gres[ti].score, c->n_cigar = gres[ti].n_cigar, c->final_task = ti;
+				if (c->score == c->last_sc) break;                                                     /* bwamem.c:1198 */
+				c->last_sc = c->score;
+				if (single || !(c->tries < 3 && c->score < reqs[k].truesc - p->a)) break;              /* bwamem.c:1201 */
+			}
+			if ((uint32_t)c->n_cigar <= tasks[c->final_task].cigar_cap)
+				c->cig = scratch + tasks[c->final_task].cigar_off;
+			else owner[n_big++] = k;
 		}
-		if (n_active == 0) break;
+		if (n_big > 0) { /* the few long CIGARs again, with the full ql+tl+2 slots */
+			bmh_glb_task_t *bt = (bmh_glb_task_t *)malloc(sizeof(*bt) * (size_t)n_big);
+			bmh_glb_result_t *br = (bmh_glb_result_t *)malloc(sizeof(*br) * (size_t)n_big);
+			size_t bs = 0;
+			if (!bt || !br) { free(bt), free(br); rc = BMH_E_NOMEM; goto done; }
+			for (k = 0; k < n_big; ++k) {
+				const cg_t *c = &cg[owner[k]];
+				bt[k] = tasks[c->final_task];
+				bt[k].cigar_off = (uint32_t)bs, bt[k].cigar_cap = (uint32_t)(c->ql + c->tl + 2);
+				bs += bt[k].cigar_cap;
+			}
+			bigscr = (uint32_t *)malloc(4 * (bs + 8));
+			rc = bigscr ? bmh_global_batch(ctx, 0, 0, bt, n_big, br, bigscr, bs + 4) : BMH_E_NOMEM;
+			for (k = 0; k < n_big && !rc; ++k) {
+				cg_t *c = &cg[owner[k]];
+				c->score = br[k].score, c->n_cigar = br[k].n_cigar;
+				c->cig = bigscr + bt[k].cigar_off;
+			}
+			free(bt), free(br);
+			if (rc) goto done;
+		}
 	}
 
 	if (trace) tt[3] = now_s();
@@ -253,7 +281,8 @@ int bmh_reg2cigar_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, const
 			rc = BMH_E_CIGAR_CAP;
 			goto done;
 		}
-		memcpy(cigar_pool + cig_used, final_cig + c->fslot, 4 * (size_t)c->n_cigar);
+		if (c->cig) memcpy(cigar_pool + cig_used, c->cig, 4 * (size_t)c->n_cigar);
+		else cigar_pool[cig_used] = (uint32_t)c->ql << 4;
 		res[k].NM = nm_md(c->n_cigar, cigar_pool + cig_used, pool + c->q_off, pool + c->t_off, c->rev, md_pool + md_used, &md_len);
 		res[k].score = c->score, res[k].n_cigar = c->n_cigar, res[k].tries = c->tries;
 		res[k].cigar_off = (uint32_t)cig_used, res[k].md_off = (uint32_t)md_used, res[k].md_len = (uint32_t)md_len;
@@ -263,6 +292,6 @@ int bmh_reg2cigar_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, const
 		fprintf(stderr, "[bwamem_hip] bmh_reg2cigar_batch %lld regions: oriented copies %.1f ms, tries %.1f ms (of which upload + GPU calls %.1f ms), NM/MD %.1f ms\n",
 		        (long long)n_req, (tt[1] - tt[0]) * 1e3, (tt[3] - tt[1]) * 1e3, tt[2] * 1e3, (now_s() - tt[3]) * 1e3);
 done:
-	free(cg), free(pool), free(tasks), free(gres), free(owner), free(scratch), free(final_cig);
+	free(cg), free(pool), free(tasks), free(gres), free(owner), free(scratch), free(bigscr);
 	return rc;
 }

@@ -762,9 +762,24 @@ int bmh_sam_batch(bmh_ctx_t *ctx, const bmh_sam_opt_t *o, const bmh_refidx_t *bn
 			reqs[j].truesc = ar->truesc, reqs[j].reg_w = ar->w;
 			cw += (size_t)(x->qe - x->qb) + (size_t)(x->re - x->rb) + 2, mb += 3 * ((size_t)(x->qe - x->qb) + (size_t)(x->re - x->rb)) + 16;
 		}
-		cig = (uint32_t *)malloc(4 * cw), md = (char *)malloc(mb);
-		if (!cig || !md) { rc = BMH_E_NOMEM; goto done; }
-		if ((rc = bmh_reg2cigar_batch(ctx, l_pac, pac, reads, (int64_t)W.n, reqs, res, cig, cw, md, mb))) goto done;
+		{ /* pools: a CIGAR may have ql+tl+1 operations and an MD 3 bytes per base, but they almost never have more than a
+		   * few -- try with 16 words / 48 bytes per region (plus one region's worst case) and only fall back to the sizes
+		   * that always suffice if the driver says BMH_E_CIGAR_CAP (hundreds of megabytes of untouched-but-mapped memory
+		   * per slice, mapped and unmapped by every host thread at once, cost more than the alignments) */
+			size_t cw2 = 16 * W.n + 70000, mb2 = 48 * W.n + 3 * 140000 + 64;
+			if (cw2 > cw) cw2 = cw;
+			if (mb2 > mb) mb2 = mb;
+			cig = (uint32_t *)malloc(4 * cw2), md = (char *)malloc(mb2);
+			if (!cig || !md) { rc = BMH_E_NOMEM; goto done; }
+			rc = bmh_reg2cigar_batch(ctx, l_pac, pac, reads, (int64_t)W.n, reqs, res, cig, cw2, md, mb2);
+			if (rc == BMH_E_CIGAR_CAP && (cw2 < cw || mb2 < mb)) {
+				free(cig), free(md);
+				cig = (uint32_t *)malloc(4 * cw), md = (char *)malloc(mb);
+				if (!cig || !md) { rc = BMH_E_NOMEM; goto done; }
+				rc = bmh_reg2cigar_batch(ctx, l_pac, pac, reads, (int64_t)W.n, reqs, res, cig, cw, md, mb);
+			}
+			if (rc) goto done;
+		}
 		for (j = 0; j < W.n; ++j) arena_words += (size_t)res[j].n_cigar + 2;
 	}
 

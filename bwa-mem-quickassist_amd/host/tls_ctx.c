@@ -39,6 +39,18 @@ static int pool_device(int nth)
 	return dev[nth % n];
 }
 
+/* Workspaces of a context that will see the shim's batches -- up to 64 k reads of phase 1 (reads, windows, SMEM tables
+ * coming back), a slice of a chunk in phase 2 -- sized once, so that no batch in the middle of a run has to grow them
+ * ($BMH_RESERVE_MB scales the figures; 0 turns the reservation off). */
+static void pool_reserve(bmh_ctx_t *ctx)
+{
+	const char *e = getenv("BMH_RESERVE_MB");
+	const size_t mb = e ? (size_t)atoi(e) : 64;
+	if (mb == 0) return;
+	(void)bmh_ctx_reserve_staging(ctx, mb << 20, mb << 20);
+	(void)bmh_ctx_reserve_device(ctx, mb << 20, (int64_t)(mb << 10) * 2, (mb << 20) / 8);
+}
+
 void bmh_tls_die(const char *msg, int code)
 {
 	fprintf(stderr, "[bwamem_hip] fatal: %s (%s)\n", msg ? msg : "?", bmh_strerror(code));
@@ -62,6 +74,7 @@ bmh_ctx_t *bmh_pool_get(const bmh_params_t *p)
 	pthread_mutex_unlock(&g_mu);
 	if (!s->ctx) {
 		if ((rc = bmh_ctx_create(&s->ctx, pool_device((int)(s - g_slots))))) bmh_tls_die("cannot create a GPU context", rc);
+		pool_reserve(s->ctx);
 	}
 	if (!s->have || memcmp(&s->params, p, sizeof(*p)) != 0) {
 		if ((rc = bmh_ctx_set_params(s->ctx, p))) bmh_tls_die(bmh_last_error(s->ctx), rc);
@@ -92,7 +105,7 @@ void bmh_pool_prewarm(int n)
 		bmh_ctx_t *ctx = 0;
 		slot_t *s = 0;
 		if (bmh_ctx_create(&ctx, pool_device(k))) return; /* no GPU: the first real call will say so loudly */
-		(void)bmh_ctx_reserve_staging(ctx, (size_t)8 << 20, (size_t)32 << 20); /* what a phase-1 batch of 8 192 reads moves */
+		pool_reserve(ctx);
 		pthread_mutex_lock(&g_mu);
 		if (g_n < BMH_POOL_MAX) s = &g_slots[g_n++], s->ctx = ctx, s->have = 0, s->busy = 0;
 		pthread_mutex_unlock(&g_mu);

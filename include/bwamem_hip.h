@@ -326,6 +326,10 @@ int bmh_driver_stats(const bmh_ctx_t *ctx, bmh_driver_stats_t *st);
  * program is still loading its index -- can reserve them here, so that the first batch does not pay for the
  * allocation.  No counterpart in the reference (it has no device). */
 int bmh_ctx_reserve_staging(bmh_ctx_t *ctx, size_t upload_bytes, size_t download_bytes);
+/* The same for the device-side workspaces of the host-buffer entry points (sequence pool, task / result records, CIGAR
+ * words, the dispatcher's sort lists): growing one of them in the middle of a run frees and re-allocates device memory,
+ * which synchronises the device under every other host thread's batch. */
+int bmh_ctx_reserve_device(bmh_ctx_t *ctx, size_t pool_bytes, int64_t max_tasks, size_t cigar_words);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Local Smith-Waterman for mate rescue and short chains.
@@ -483,7 +487,7 @@ typedef struct bmh_smem_call { /* one bwt_smem1 call and where its result interv
 	uint32_t rsv;
 } bmh_smem_call_t;
 
-/* The index files of `bwa index` (<prefix>.bwt/.sa/.ann/.pac; reference bwt.c:380-421, bntseq.c:94-140, bwa.c:291)
+/* The index files of `bwa index` (<prefix>.bwt/.sa/.ann/.amb/.pac; reference bwt.c:380-421, bntseq.c:94-150, bwa.c:291)
  * read into plain arrays: what bmh_ctx_set_bwt / bmh_ctx_set_pac take.  Host I/O only, no GPU involved. */
 typedef struct bmh_index {
 	bmh_bwt_t bwt;    /* arrays owned by the index */
@@ -493,6 +497,10 @@ typedef struct bmh_index {
 	char **names;
 	int64_t *offsets;
 	int32_t *lens;
+	int32_t n_holes;  /* runs of ambiguous bases (.amb; bntamb1_t, bntseq.h:47-51): start, length, the letter */
+	int64_t *hole_offsets;
+	int32_t *hole_lens;
+	char *hole_chars;
 } bmh_index_t;
 int bmh_index_load(const char *prefix, bmh_index_t **out); /* BMH_E_ARG if a file is missing or inconsistent */
 void bmh_index_free(bmh_index_t *ix);
