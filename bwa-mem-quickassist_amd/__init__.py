@@ -43,7 +43,7 @@ SW_RES = np.dtype([("score", "<i4"), ("te", "<i4"), ("qe", "<i4"), ("score2", "<
 KSW_XBYTE, KSW_XSTOP, KSW_XSUBO, KSW_XSTART = 0x10000, 0x20000, 0x40000, 0x80000  # reference ksw.h:6-9
 SMEM_INTV = np.dtype([("x0", "<u8"), ("x1", "<u8"), ("x2", "<u8"), ("info", "<u8")])
 SMEM_CALL = np.dtype([("x", "<i4"), ("min_intv", "<i4"), ("ret", "<i4"), ("n", "<i4"), ("first", "<u4"), ("rsv", "<u4")])
-SMEM_OPT = np.dtype([("min_seed_len", "<i4"), ("split_len", "<i4"), ("split_width", "<i4"), ("start_width", "<i4")])
+SMEM_OPT = np.dtype([("min_seed_len", "<i4"), ("split_len", "<i4"), ("split_width", "<i4"), ("start_width", "<i4"), ("min_emit_len", "<i4")])
 
 
 class _Bwt(C.Structure):  # bmh_bwt_t
@@ -297,7 +297,9 @@ class Context:
         """The bwt_smem1 calls of smem_next2's iteration for every read (reference bwt.c:288, bwamem.c:118).
         Returns per read (SMEM_CALL[], SMEM_INTV[])."""
         n = len(reads)
-        opt = np.ascontiguousarray(opt, dtype=SMEM_OPT)
+        o_in, opt = np.asarray(opt), np.zeros((), dtype=SMEM_OPT)
+        for k in o_in.dtype.names:  # (records written before a field existed leave it 0)
+            opt[k] = o_in[k]
         keep = []
         c_reads = (_Read * max(n, 1))()
         tot = 0

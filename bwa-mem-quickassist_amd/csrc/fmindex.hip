@@ -198,19 +198,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
 			const int ret = fm_smem1(B, len, q, x1, O.start_width, s0, s1, sm, &n);
 			start = ret;
 			// the longest match, first of equals (sm holds them back to front)
-			int mx = 0, mxk = 0;
+			int mx = 0, mxk = 0, ne = 0; // ne = intervals long enough to be returned (bmh_smem_opt_t.min_emit_len)
 			for (int i = 0; i < n; ++i) {
 				const Intv v = sm[n - 1 - i];
 				const int l = (int)((uint32_t)v.info - (uint32_t)(v.info >> 32));
 				if (mx < l) mx = l, mxk = n - 1 - i;
+				ne += l >= O.min_emit_len;
 			}
 			// write call 1
-			unsigned long long ci = atomicAdd(&cursors[0], 1ull), base = atomicAdd(&cursors[1], (unsigned long long)n);
-			if (ci < call_cap && base + n <= intv_cap) {
+			unsigned long long ci = atomicAdd(&cursors[0], 1ull), base = atomicAdd(&cursors[1], (unsigned long long)ne);
+			if (ci < call_cap && base + ne <= intv_cap) {
 				bmh_smem_call_t c;
-				c.x = x1, c.min_intv = O.start_width, c.ret = ret, c.n = n, c.first = (uint32_t)base, c.rsv = (uint32_t)seq;
+				c.x = x1, c.min_intv = O.start_width, c.ret = ret, c.n = ne, c.first = (uint32_t)base, c.rsv = (uint32_t)seq;
 				calls[ci] = c, call_read[ci] = (uint32_t)r;
-				for (int i = 0; i < n; ++i) intv[base + i] = sm[n - 1 - i];
+				for (int i = 0, k = 0; i < n; ++i) {
+					const Intv v = sm[n - 1 - i];
+					if ((int)((uint32_t)v.info - (uint32_t)(v.info >> 32)) >= O.min_emit_len) intv[base + k++] = v;
+				}
 			} else atomicExch(overflow, 1);
 			++seq;
 			bool split = false;
@@ -220,12 +224,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
 			}
 			if (split) { // re-seeding from the middle of the longest match
 				ret2 = fm_smem1(B, len, q, x2, mi2, s0, s1, sm, &n2);
-				ci = atomicAdd(&cursors[0], 1ull), base = atomicAdd(&cursors[1], (unsigned long long)n2);
-				if (ci < call_cap && base + n2 <= intv_cap) {
+				int ne2 = 0;
+				for (int i = 0; i < n2; ++i) {
+					const Intv v = sm[i];
+					ne2 += (int)((uint32_t)v.info - (uint32_t)(v.info >> 32)) >= O.min_emit_len;
+				}
+				ci = atomicAdd(&cursors[0], 1ull), base = atomicAdd(&cursors[1], (unsigned long long)ne2);
+				if (ci < call_cap && base + ne2 <= intv_cap) {
 					bmh_smem_call_t c;
-					c.x = x2, c.min_intv = mi2, c.ret = ret2, c.n = n2, c.first = (uint32_t)base, c.rsv = (uint32_t)seq;
+					c.x = x2, c.min_intv = mi2, c.ret = ret2, c.n = ne2, c.first = (uint32_t)base, c.rsv = (uint32_t)seq;
 					calls[ci] = c, call_read[ci] = (uint32_t)r;
-					for (int i = 0; i < n2; ++i) intv[base + i] = sm[n2 - 1 - i];
+					for (int i = 0, k = 0; i < n2; ++i) {
+						const Intv v = sm[n2 - 1 - i];
+						if ((int)((uint32_t)v.info - (uint32_t)(v.info >> 32)) >= O.min_emit_len) intv[base + k++] = v;
+					}
 				} else atomicExch(overflow, 1);
 				++seq;
 			}
@@ -274,19 +286,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
 
 	// the call is over: emit it (smem_next2's bookkeeping, bwamem.c:118-162) and decide what comes next
 	auto finish_call = [&](int n, int ret_) {
-		int mx = 0, mxk = 0;
-		if (!is_split)
-			for (int k = 0; k < n; ++k) { // the longest match, first of equals (mem holds them back to front)
-				const Intv v = mem[n - 1 - k];
-				const int l = (int)((uint32_t)v.info - (uint32_t)(v.info >> 32));
-				if (mx < l) mx = l, mxk = n - 1 - k;
-			}
-		const unsigned long long ci = atomicAdd(&cursors[0], 1ull), base = atomicAdd(&cursors[1], (unsigned long long)n);
-		if (ci < call_cap && base + n <= intv_cap) {
+		int mx = 0, mxk = 0, ne = 0; // ne = intervals long enough to be returned (bmh_smem_opt_t.min_emit_len)
+		uint64_t longm = 0;          // ... which ones, for calls of up to 64 intervals (more: the lengths are read again)
+		for (int k = 0; k < n; ++k) { // the longest match, first of equals (mem holds them back to front)
+			const uint64_t info = mem[n - 1 - k].info;
+			const int l = (int)((uint32_t)info - (uint32_t)(info >> 32));
+			if (!is_split && mx < l) mx = l, mxk = n - 1 - k;
+			if (l >= O.min_emit_len) ++ne, longm |= k < 64 ? 1ull << k : 0ull;
+		}
+		const unsigned long long ci = atomicAdd(&cursors[0], 1ull), base = atomicAdd(&cursors[1], (unsigned long long)ne);
+		if (ci < call_cap && base + ne <= intv_cap) {
 			bmh_smem_call_t c;
-			c.x = x, c.min_intv = is_split ? mi2 : O.start_width, c.ret = ret_, c.n = n, c.first = (uint32_t)base, c.rsv = (uint32_t)seq;
+			c.x = x, c.min_intv = is_split ? mi2 : O.start_width, c.ret = ret_, c.n = ne, c.first = (uint32_t)base, c.rsv = (uint32_t)seq;
 			calls[ci] = c, call_read[ci] = (uint32_t)r;
-			for (int k = 0; k < n; ++k) intv[base + k] = mem[n - 1 - k];
+			for (int k = 0, w = 0; k < n && w < ne; ++k) {
+				if (k < 64 && !(longm >> k & 1)) continue;
+				const Intv v = mem[n - 1 - k];
+				if (k < 64 || (int)((uint32_t)v.info - (uint32_t)(v.info >> 32)) >= O.min_emit_len) intv[base + w++] = v;
+			}
 		} else atomicExch(overflow, 1);
 		++seq;
 		if (!is_split) {

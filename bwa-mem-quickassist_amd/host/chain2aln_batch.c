@@ -326,10 +326,12 @@ static int request(drv_t *d, req_t *q, int r, const rstate_t *rs, int ci, int si
 	return 0;
 }
 
-static double now_s(void)
+static double now_s(void) /* the clock of the BMH_DRIVER_TRACE lines: wall time, or with BMH_TRACE_CPU this thread's CPU time */
 {
+	static int cpu = -1;
 	struct timespec ts;
-	clock_gettime(CLOCK_MONOTONIC, &ts);
+	if (cpu < 0) cpu = getenv("BMH_TRACE_CPU") != 0;
+	clock_gettime(cpu ? CLOCK_THREAD_CPUTIME_ID : CLOCK_MONOTONIC, &ts);
 	return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 
@@ -353,7 +355,7 @@ static int chains2regs(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n_
                        const bmh_chain_v *chains, bmh_chain_pre_fn pre, void *pre_ud, int short_msl, bmh_alnreg_v *regs)
 {
 	const int trace = getenv("BMH_DRIVER_TRACE") != 0; /* where a call's time goes, on stderr */
-	double t_trace[4] = {0, 0, 0, 0};
+	double t_trace[4] = {0, 0, 0, 0}, t_fine[4] = {0, 0, 0, 0};
 	drv_t d;
 	rstate_t *rs = 0;
 	chain_win_t *wins = 0;
@@ -421,6 +423,7 @@ static int chains2regs(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n_
 		if (wins[ci_flat].sw_idx >= 0) wins[ci_flat].swin_off = pool_bytes, pool_bytes += (size_t)(wins[ci_flat].sre - wins[ci_flat].srb);
 	}
 	d.wins = wins;
+	if (trace) t_fine[0] = now_s();
 
 	/* pass 2: fill and upload the pool once */
 	pool = (uint8_t *)malloc(pool_bytes + 16);
@@ -435,7 +438,9 @@ static int chains2regs(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n_
 	}
 	memset(pool + pool_bytes, 0, 16);
 	d.st.pool_bytes = (int64_t)pool_bytes + 16;
+	if (trace) t_fine[1] = now_s();
 	if ((rc = bmh_upload_pool(ctx, pool, pool_bytes + 16))) goto done;
+	if (trace) t_fine[2] = now_s();
 	if (n_short) { /* every ksw_align2 of the batch's mem_chain2aln_short calls (bwamem.c:529-531) as one GPU batch */
 		sw_tasks = (bmh_sw_task_t *)calloc(n_short, sizeof(bmh_sw_task_t));
 		sw_res = (bmh_sw_result_t *)malloc(sizeof(bmh_sw_result_t) * n_short);
@@ -523,8 +528,9 @@ static int chains2regs(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, int n_
 	}
 	d.st.seeds_speculated -= d.st.seeds_extended; /* extended on the device but never used */
 	if (trace)
-		fprintf(stderr, "[bwamem_hip] bmh_chain2aln_batch %d reads: windows+pool+upload %.1f ms, %lld rounds: GPU calls %.1f ms, replay %.1f ms; %lld seeds extended, %lld speculated in vain\n",
-		        n_reads, (t_trace[1] - t_trace[0]) * 1e3, (long long)d.st.rounds, t_trace[2] * 1e3, (now_s() - t_trace[1] - t_trace[2]) * 1e3,
+		fprintf(stderr, "[bwamem_hip] bmh_chain2aln_batch %d reads: windows+pool+upload %.1f ms (windows %.1f ms, pool %.1f ms, upload %.1f ms, short-chain SW %.1f ms), %lld rounds: GPU calls %.1f ms, replay %.1f ms; %lld seeds extended, %lld speculated in vain\n",
+		        n_reads, (t_trace[1] - t_trace[0]) * 1e3, (t_fine[0] - t_trace[0]) * 1e3, (t_fine[1] - t_fine[0]) * 1e3, (t_fine[2] - t_fine[1]) * 1e3,
+		        (t_trace[1] - t_fine[2]) * 1e3, (long long)d.st.rounds, t_trace[2] * 1e3, (now_s() - t_trace[1] - t_trace[2]) * 1e3,
 		        (long long)d.st.seeds_extended, (long long)d.st.seeds_speculated);
 done:
 	if (rs) for (r = 0; r < n_reads; ++r) free(rs[r].srt);

@@ -17,6 +17,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <pthread.h>
 #include <semaphore.h>
@@ -109,6 +110,15 @@ typedef struct { int l_seq; char *name, *comment, *seq, *qual, *sam; } ref_bseq1
 /* what this shim still takes from the host program: its base-code table and its clocks (bntseq.c, utils.c) */
 extern unsigned char nst_nt4_table[256];
 extern double cputime(void), realtime(void);
+static double stage_now(void) /* the clock of the BMH_VERBOSE thread-second sums: wall time, or with BMH_TRACE_CPU the thread's CPU time */
+{
+	static int cpu = -1;
+	struct timespec ts;
+	if (cpu < 0) cpu = getenv("BMH_TRACE_CPU") != 0;
+	if (!cpu) return realtime();
+	clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+	return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 
 /* ---- seeding: the batch's FM-index queries on the GPU, chaining on top of them -----------------------------------------
  * mem_chain (bwamem.c:283) = SMEM search (smem_next2 -> bwt_smem1) + suffix-array look-ups (bwt_sa) + chaining in a
@@ -134,7 +144,7 @@ typedef struct {
 	uint64_t *sa_k, *sa_pos; /* per interval: where its run of positions starts (bmh_chain_sa_keys); the positions */
 	size_t n_sa;
 } qa_seed_t;
-static double g_seed_density[2] = {0.06, 0.35};
+static double g_seed_density[2] = {0.06, 0.02};
 static long long g_seed_us[3]; /* thread-microseconds: bmh_smem_batch, building the look-up keys, bmh_sa_batch */
 static __thread qa_seed_t *qa_seed; /* the batch this thread is chaining */
 
@@ -154,12 +164,13 @@ static void qa_seed_batch_begin(bmh_ctx_t *ctx, const ref_mem_opt_t *opt, const 
 	if ((rc = bmh_ctx_set_bwt(ctx, &ib))) bmh_tls_die(bmh_last_error(ctx), rc);
 	so.min_seed_len = opt->min_seed_len, so.split_len = (int)(opt->min_seed_len * opt->split_factor + .499); /* bwamem.c:211 */
 	so.split_width = opt->split_width, so.start_width = (opt->flag & REF_MEM_F_NO_EXACT) ? 2 : 1;           /* bwamem.c:212 */
+	so.min_emit_len = opt->min_seed_len; /* shorter intervals are never turned into seeds (bwamem.c:219): they stay on the device */
 	for (r = 0; r < n; ++r) tot += (size_t)reads[r].l_seq;
 	S = (qa_seed_t *)calloc(1, sizeof(*S));
 	S->bwt = bwt, S->n_reads = n, S->reads = reads;
 	S->call_off = (uint32_t *)malloc(4 * ((size_t)n + 1)), S->intv_off = (uint64_t *)malloc(8 * ((size_t)n + 1));
 	/* output arrays sized from the densest batch seen so far in this process (calls / intervals per base) */
-	ts[0] = realtime();
+	ts[0] = stage_now();
 	for (call_cap = (size_t)(g_seed_density[0] * 1.3 * (double)tot) + 4 * (size_t)n + 64,
 	    intv_cap = (size_t)(g_seed_density[1] * 1.3 * (double)tot) + 1024;;
 	     call_cap *= 2, intv_cap *= 2) {
@@ -170,7 +181,7 @@ static void qa_seed_batch_begin(bmh_ctx_t *ctx, const ref_mem_opt_t *opt, const 
 		free(S->calls), free(S->intv);
 	}
 	if (rc) bmh_tls_die(bmh_last_error(ctx), rc);
-	ts[1] = realtime();
+	ts[1] = stage_now();
 	if (tot) { /* (a benign race: statistics that only size buffers) */
 		const double dc = (double)S->call_off[n] / (double)tot, di = (double)S->intv_off[n] / (double)tot;
 		if (dc > g_seed_density[0]) g_seed_density[0] = dc;
@@ -186,10 +197,10 @@ static void qa_seed_batch_begin(bmh_ctx_t *ctx, const ref_mem_opt_t *opt, const 
 		bmh_chain_sa_keys(&co, S->intv_off[n], S->intv, S->sa_k, keys);
 		S->n_sa = nk;
 	}
-	ts[2] = realtime();
+	ts[2] = stage_now();
 	if ((rc = bmh_sa_batch(ctx, keys, (int64_t)nk, S->sa_pos))) bmh_tls_die(bmh_last_error(ctx), rc);
 	free(keys);
-	ts[3] = realtime();
+	ts[3] = stage_now();
 	__sync_fetch_and_add(&g_seed_us[0], (long long)((ts[1] - ts[0]) * 1e6)), __sync_fetch_and_add(&g_seed_us[1], (long long)((ts[2] - ts[1]) * 1e6));
 	__sync_fetch_and_add(&g_seed_us[2], (long long)((ts[3] - ts[2]) * 1e6));
 	qa_seed = S;
@@ -226,11 +237,11 @@ bmh_alnreg_v *mem_align1_core_batched(const ref_mem_opt_t *opt, const void *bwt,
 	p.o_del = opt->o_del, p.e_del = opt->e_del, p.o_ins = opt->o_ins, p.e_ins = opt->e_ins, p.zdrop = opt->zdrop;
 	p.a = opt->a, p.w = opt->w, p.pen_clip5 = opt->pen_clip5, p.pen_clip3 = opt->pen_clip3;
 	memcpy(p.mat, opt->mat, 25);
-	tq[0] = tq[1] = realtime();
+	tq[0] = tq[1] = stage_now();
 	ctx = bmh_pool_get(&p);
 	qa_seed_batch_begin(ctx, opt, (const ref_bwt_t *)bwt, batch_size, reads); /* SMEMs + suffix-array look-ups of the batch on the GPU */
 	bmh_pool_put(ctx);
-	tq[2] = realtime();
+	tq[2] = stage_now();
 	{ /* chaining: mem_chain + mem_chain_flt (bwamem.c:1095-1097) over the batch's tables */
 		const qa_seed_t *S = qa_seed;
 		bmh_chain_opt_t co;
@@ -246,8 +257,8 @@ bmh_alnreg_v *mem_align1_core_batched(const ref_mem_opt_t *opt, const void *bwt,
 		}
 	}
 	qa_seed_batch_end();
-	tq[3] = realtime();
-	tq[4] = realtime();
+	tq[3] = stage_now();
+	tq[4] = stage_now();
 	ctx = bmh_pool_get(&p);
 	{ /* reference resident in HBM, shared by all contexts: the kernels do bns_get_seq themselves.  BMH_PAC_RESIDENT=0
 	   * falls back to host-decoded windows in the pool. */
@@ -263,7 +274,7 @@ bmh_alnreg_v *mem_align1_core_batched(const ref_mem_opt_t *opt, const void *bwt,
 		__sync_fetch_and_add(&g_p1_cnt[3], st.short_sw);
 	}
 	bmh_pool_put(ctx);
-	tq[5] = realtime();
+	tq[5] = stage_now();
 	{ /* thread-seconds per stage, summed over the run (BMH_VERBOSE prints them per chunk) */
 		static const int a_[5] = {0, 1, 2, 3, 4};
 		int k;
@@ -389,13 +400,13 @@ static void qa_sam_slice(void *data, int k, int tid)
 	int rc, i;
 	(void)tid;
 	if (hi <= lo) return;
-	t0 = t1 = realtime();
+	t0 = t1 = stage_now();
 	ctx = qa_slice_ctx(J);
 	if ((rc = bmh_sam_batch(ctx, J->sopt, (const bmh_refidx_t *)J->bns, J->pac, J->pes, J->n_processed + lo, hi - lo, (bmh_seq_t *)(J->seqs + lo),
 	                        J->regs + lo, bwa_rg_id)))
 		bmh_tls_die(rc == BMH_E_ARG ? "a region could not be turned into an alignment (the reference aborts here too, bwamem.c:1183-1186)" : bmh_last_error(ctx), rc);
 	bmh_pool_put(ctx);
-	t2 = realtime();
+	t2 = stage_now();
 	for (i = lo; i < hi; ++i) free(J->regs[i].a);
 	__sync_fetch_and_add(&g_sam_us[0], (long long)((t1 - t0) * 1e6)), __sync_fetch_and_add(&g_sam_us[1], (long long)((t2 - t1) * 1e6));
 }

@@ -25,11 +25,40 @@
 const bmh_params_t *bmh_ctx_params_(const bmh_ctx_t *ctx);
 int bmh_upload_pool(bmh_ctx_t *ctx, const uint8_t *pool, size_t bytes);
 
-static double now_s(void)
+static double now_s(void) /* the clock of the BMH_DRIVER_TRACE lines: wall time, or with BMH_TRACE_CPU this thread's CPU time */
 {
+	static int cpu = -1;
 	struct timespec ts;
-	clock_gettime(CLOCK_MONOTONIC, &ts);
+	if (cpu < 0) cpu = getenv("BMH_TRACE_CPU") != 0;
+	clock_gettime(cpu ? CLOCK_THREAD_CPUTIME_ID : CLOCK_MONOTONIC, &ts);
 	return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* [beg,end) of the 2-bit reference as one code per byte (comp: complemented), four bases per table look-up: the per-base
+ * form (bntseq.c:355-376) is a third of this driver's host time on 150 bp regions. */
+static uint32_t pac_lut[2][256];
+static volatile int pac_lut_ready;
+static void pac_codes(const uint8_t *pac, int64_t beg, int64_t end, int comp, uint8_t *dst)
+{
+	int64_t x = beg;
+	const uint32_t *lut;
+	if (!pac_lut_ready) { /* (filled with the same values by whoever gets here first: a benign race) */
+		int b, j;
+		for (b = 0; b < 256; ++b) {
+			uint32_t f = 0, c = 0;
+			for (j = 0; j < 4; ++j) {
+				const uint32_t v = (uint32_t)(b >> ((3 - j) << 1) & 3);
+				f |= v << (8 * j), c |= (3 - v) << (8 * j);
+			}
+			pac_lut[0][b] = f, pac_lut[1][b] = c;
+		}
+		__sync_synchronize();
+		pac_lut_ready = 1;
+	}
+	lut = pac_lut[comp != 0];
+	for (; x < end && (x & 3); ++x) *dst++ = (uint8_t)(lut[pac[x >> 2]] >> ((x & 3) << 3));
+	for (; x + 4 <= end; x += 4, dst += 4) memcpy(dst, &lut[pac[x >> 2]], 4);
+	for (; x < end; ++x) *dst++ = (uint8_t)(lut[pac[x >> 2]] >> ((x & 3) << 3));
 }
 
 enum { SMALL_CAP = 24 }; /* CIGAR slots reserved per task on the first attempt of a try */
@@ -148,14 +177,12 @@ int bmh_reg2cigar_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, const
 		if (!c->valid) continue;
 		rq = reads[r->read].seq + r->qb, q = pool + c->q_off, t = pool + c->t_off;
 		if (!c->rev) {
-			int64_t x;
 			memcpy(q, rq, (size_t)c->ql);
-			for (x = r->rb, i = 0; x < r->re; ++x, ++i) t[i] = (uint8_t)(pac[x >> 2] >> ((~x & 3) << 1) & 3);
+			pac_codes(pac, r->rb, r->re, 0, t);
 		} else { /* reverse-strand window = complement read backwards (bntseq.c:364-368), then reversed again (bwa.c:105) */
 			const int64_t lo = (l_pac << 1) - 1 - r->re; /* forward coordinates (lo, hi] */
-			int64_t x;
 			for (i = 0; i < c->ql; ++i) q[i] = rq[c->ql - 1 - i];
-			for (x = lo + 1, i = 0; i < c->tl; ++x, ++i) t[i] = (uint8_t)(3 - (pac[x >> 2] >> ((~x & 3) << 1) & 3));
+			pac_codes(pac, lo + 1, lo + 1 + c->tl, 1, t);
 		}
 		tmp = infer_bw(c->ql, c->tl, r->truesc, p->a, p->o_del, p->e_del);
 		c->w2 = infer_bw(c->ql, c->tl, r->truesc, p->a, p->o_ins, p->e_ins);

@@ -29,10 +29,12 @@
 #include "../../include/bwamem_hip.h"
 #include "sort_exact.h"
 
-static double now_s(void)
+static double now_s(void) /* the clock of the BMH_DRIVER_TRACE lines: wall time, or with BMH_TRACE_CPU this thread's CPU time */
 {
+	static int cpu = -1;
 	struct timespec ts;
-	clock_gettime(CLOCK_MONOTONIC, &ts);
+	if (cpu < 0) cpu = getenv("BMH_TRACE_CPU") != 0;
+	clock_gettime(cpu ? CLOCK_THREAD_CPUTIME_ID : CLOCK_MONOTONIC, &ts);
 	return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
 

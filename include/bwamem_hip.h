@@ -479,6 +479,10 @@ typedef struct bmh_smem_opt {
 	int32_t split_len;    /* (int)(min_seed_len*split_factor + .499), bwamem.c:211 (clamped to the read length there) */
 	int32_t split_width;  /* mem_opt_t.split_width                                                              */
 	int32_t start_width;  /* 2 with MEM_F_NO_EXACT, else 1, bwamem.c:212                                        */
+	int32_t min_emit_len; /* 0: every interval of every call comes back, like bwt_smem1.  > 0: only intervals at least this
+	                       * long do (call.n counts those) -- all that mem_insert_seed looks at with min_emit_len <=
+	                       * min_seed_len (bwamem.c:219), about one interval in twenty on 150 bp reads; the calls made, their
+	                       * arguments and return values are the same either way                                       */
 } bmh_smem_opt_t;
 typedef struct bmh_smem_call { /* one bwt_smem1 call and where its result intervals lie */
 	int32_t x, min_intv; /* arguments (bwt.c:288)                         */

@@ -156,7 +156,7 @@ int orc_smem_calls(const bmh_bwt_t *b, const bmh_smem_opt_t *o, int len, const u
 	const int split_len = o->split_len < len ? o->split_len : len; /* bwamem.c:213 */
 	int start = 0, nc = 0, used = 0;
 	while (start < len) { /* smem_next2, bwamem.c:118-162 */
-		int n, i, mx = 0, mx_i = 0, ret;
+		int n, i, mx = 0, mx_i = 0, ret, n_rec = 1; /* n_rec: calls of this round (2 with re-seeding) */
 		while (start < len && q[start] > 3) ++start;
 		if (start == len) break;
 		if (nc + 2 > call_cap || used + 2 * (len + 1) > pool_cap) return -1;
@@ -175,7 +175,17 @@ int orc_smem_calls(const bmh_bwt_t *b, const bmh_smem_opt_t *o, int len, const u
 			ret = orc_bwt_smem1(b, len, q, mid, mi, pool + used + n, &n2);
 			calls[nc].x = mid, calls[nc].min_intv = mi, calls[nc].ret = ret, calls[nc].n = n2;
 			calls[nc].first = (uint32_t)(used + n), calls[nc].rsv = 0, ++nc;
-			n += n2;
+			n += n2, n_rec = 2;
+		}
+		if (o->min_emit_len > 0) { /* bmh_smem_opt_t.min_emit_len: hand back the long intervals only, order kept */
+			int k, w = used, rd = used;
+			for (k = nc - n_rec; k < nc; ++k) {
+				const int cn = calls[k].n;
+				calls[k].first = (uint32_t)w, calls[k].n = 0;
+				for (i = 0; i < cn; ++i, ++rd)
+					if ((int)((uint32_t)pool[rd].info - (uint32_t)(pool[rd].info >> 32)) >= o->min_emit_len) pool[w++] = pool[rd], ++calls[k].n;
+			}
+			n = w - used;
 		}
 		used += n;
 	}

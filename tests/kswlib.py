@@ -554,7 +554,7 @@ def golden_matesw_groups():
 # ---- FM-index (seeding) ---------------------------------------------------------------------------------------------
 SMEM_INTV = np.dtype([("x0", "<u8"), ("x1", "<u8"), ("x2", "<u8"), ("info", "<u8")])
 SMEM_CALL = np.dtype([("x", "<i4"), ("min_intv", "<i4"), ("ret", "<i4"), ("n", "<i4"), ("first", "<u4"), ("rsv", "<u4")])
-SMEM_OPT = np.dtype([("min_seed_len", "<i4"), ("split_len", "<i4"), ("split_width", "<i4"), ("start_width", "<i4")])
+SMEM_OPT = np.dtype([("min_seed_len", "<i4"), ("split_len", "<i4"), ("split_width", "<i4"), ("start_width", "<i4"), ("min_emit_len", "<i4")])
 
 
 class CBwt(C.Structure):  # bmh_bwt_t
@@ -575,6 +575,15 @@ def make_cbwt(primary, L2, seq_len, bwt_words, sa_intv, sa, keep):
     return b
 
 
+def smem_opt(opt):
+    """A bmh_smem_opt_t record from one that may predate a field (the fixtures hold the first four): missing fields are 0."""
+    opt = np.asarray(opt)
+    out = np.zeros((), dtype=SMEM_OPT)
+    for k in opt.dtype.names:
+        out[k] = opt[k]
+    return out
+
+
 def orc_smem_calls(cb, opt, read):
     """OUR restatement of the bwt_smem1 call sequence of one read -> (SMEM_CALL[], SMEM_INTV[])."""
     lib = load_oracle()
@@ -583,7 +592,7 @@ def orc_smem_calls(cb, opt, read):
     calls = np.zeros(2 * L + 4, dtype=SMEM_CALL)
     pool = np.zeros(4 * (L + 2) * 4 + 64, dtype=SMEM_INTV)
     used = C.c_int(0)
-    oo = np.ascontiguousarray(opt, dtype=SMEM_OPT)
+    oo = smem_opt(opt)
     lib.orc_smem_calls.restype = C.c_int
     n = lib.orc_smem_calls(C.byref(cb), oo.ctypes.data_as(C.c_void_p), C.c_int(L), read.ctypes.data_as(C.c_void_p),
                            calls.ctypes.data_as(C.c_void_p), C.c_int(len(calls)), pool.ctypes.data_as(C.c_void_p),
@@ -609,4 +618,4 @@ def golden_fmindex():
         reads.append(g["reads"][o:o + L].copy())
         per.append((g["calls"][c0:c0 + cn].copy(), g["intv"][i0:i0 + inn].copy()))
         o, c0, i0 = o + L, c0 + cn, i0 + inn
-    return cb, keep, raw, g["opt"], reads, per, g["sa_k"], g["sa_pos"]
+    return cb, keep, raw, smem_opt(g["opt"]), reads, per, g["sa_k"], g["sa_pos"]

@@ -64,3 +64,26 @@ def test_oracle_fmindex_matches_reference_live(tmp_path):
         for v in its:
             assert all(tuple(int(w[f]) for f in ("x0", "x1", "x2", "info")) in have for w in v)
     assert n_calls > 1000
+
+
+def test_oracle_min_emit_len_is_a_pure_filter():
+    """bmh_smem_opt_t.min_emit_len hands back the long intervals of the same calls, in the same order."""
+    cb, keep, raw, opt, reads, per, sa_k, sa_pos = kswlib.golden_fmindex()
+    o2 = np.array(opt, dtype=kswlib.SMEM_OPT).copy()
+    o2["min_emit_len"] = int(o2["min_seed_len"])
+    n_short = 0
+    for rd in reads:
+        calls, pool = kswlib.orc_smem_calls(cb, opt, rd)
+        fc, fp = kswlib.orc_smem_calls(cb, o2, rd)
+        assert len(fc) == len(calls)
+        want = []
+        for c, f in zip(calls, fc):
+            assert all(int(c[k]) == int(f[k]) for k in ("x", "min_intv", "ret"))
+            iv = pool[int(c["first"]): int(c["first"]) + int(c["n"])]
+            ln = (iv["info"] & np.uint64(0xffffffff)).astype(np.int64) - (iv["info"] >> np.uint64(32)).astype(np.int64)
+            long_ = iv[ln >= int(o2["min_emit_len"])]
+            n_short += len(iv) - len(long_)
+            assert int(f["n"]) == len(long_) and (fp[int(f["first"]): int(f["first"]) + int(f["n"])] == long_).all()
+            want.append(long_)
+        assert len(fp) == sum(len(w) for w in want)
+    assert n_short > 100

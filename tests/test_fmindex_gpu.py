@@ -57,3 +57,33 @@ def test_smem_matches_oracle_on_many_reads(kernel, monkeypatch):
     ks = rng.integers(0, raw[2] + 1, 20000).astype(np.uint64)
     assert (ctx.sa_batch(ks) == kswlib.orc_sa(cb, ks)).all()
     ctx.close()
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_smem_min_emit_len_returns_the_long_intervals_only(kernel, monkeypatch):
+    """What the preload shim asks for: the same calls, only the intervals chaining can use (length >= min_seed_len)."""
+    monkeypatch.setenv("BMH_SMEM_KERNEL", kernel)
+    cb, keep, raw, opt, reads, per, sa_k, sa_pos = kswlib.golden_fmindex()
+    o2 = np.array(opt, dtype=kswlib.SMEM_OPT).copy()
+    o2["min_emit_len"] = int(o2["min_seed_len"])
+    rng = np.random.default_rng(193)
+    src = np.concatenate(reads)
+    more = list(reads)
+    for _ in range(2000):
+        L = int(rng.choice([1, 19, 20, 75, 150, 151, 300]))
+        p = int(rng.integers(0, len(src) - L))
+        rd = src[p:p + L].copy()
+        m = rng.random(L) < rng.choice([0.02, 0.12])
+        rd[m] = (rd[m] + rng.integers(1, 4, m.sum())) % 5
+        more.append(rd)
+    ctx = _ctx_with({})
+    ctx.set_bwt(*raw)
+    got = ctx.smem_batch(o2, more)
+    full = ctx.smem_batch(opt, more)
+    n_kept = n_all = 0
+    for r, (g, rd) in enumerate(zip(got, more)):
+        assert _same_calls(g, kswlib.orc_smem_calls(cb, o2, rd)), f"read {r} (len {len(rd)})"
+        n_kept += len(g[1])
+        n_all += len(full[r][1])
+    assert 0 < n_kept < n_all / 4
+    ctx.close()
