@@ -14,6 +14,7 @@
 namespace bmh {
 
 bmh_gate_fn g_gate_enter = nullptr, g_gate_leave = nullptr;
+int g_wait_blocking = 0;
 
 int set_hip_error(bmh_ctx *ctx, hipError_t e, const char *what)
 {
@@ -67,11 +68,11 @@ static void free_buf(DevBuf &b)
 static int fetch_err(bmh_ctx *ctx)
 {
 	BMH_HIP(ctx, hipMemcpyAsync(ctx->h_err, ctx->d_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-	BMH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	BMH_HIP(ctx, stream_wait(ctx, ctx->stream));
 	int e = *ctx->h_err;
 	if (e != 0) {
 		BMH_HIP(ctx, hipMemsetAsync(ctx->d_err, 0, sizeof(int), ctx->stream));
-		BMH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		BMH_HIP(ctx, stream_wait(ctx, ctx->stream));
 		ctx->last_error = "a task was outside the supported range (see bwamem_hip.h)";
 	}
 	return e;
@@ -135,6 +136,8 @@ extern "C" {
 
 int bmh_version(void) { return BMH_VERSION; }
 
+void bmh_set_wait_mode(int blocking) { bmh::g_wait_blocking = blocking != 0; }
+
 int bmh_set_device_gate(bmh_gate_fn enter, bmh_gate_fn leave)
 {
 	if ((enter == nullptr) != (leave == nullptr)) return BMH_E_ARG;
@@ -181,7 +184,8 @@ int bmh_ctx_create(bmh_ctx_t **out, int device)
 	if (!ctx) return BMH_E_NOMEM;
 	ctx->device = device;
 	hipError_t e;
-	if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess ||
+	if ((e = hipSetDevice(device)) == hipSuccess && g_wait_blocking) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync); // (also covers hipMemcpy / hipFree)
+	if (e != hipSuccess || (e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess ||
 	    (e = hipMalloc((void **)&ctx->d_err, sizeof(int))) != hipSuccess || (e = hipMemset(ctx->d_err, 0, sizeof(int))) != hipSuccess ||
 	    (e = hipHostMalloc((void **)&ctx->h_err, sizeof(int), hipHostMallocDefault)) != hipSuccess ||
 	    (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess ||
@@ -189,7 +193,8 @@ int bmh_ctx_create(bmh_ctx_t **out, int device)
 	    (e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)) != hipSuccess ||
 	    (e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming)) != hipSuccess ||
 	    (e = hipStreamCreateWithFlags(&ctx->aux2_stream, hipStreamNonBlocking)) != hipSuccess ||
-	    (e = hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming)) != hipSuccess) {
+	    (e = hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming)) != hipSuccess ||
+	    (e = hipEventCreateWithFlags(&ctx->ev_wait, hipEventDisableTiming | hipEventBlockingSync)) != hipSuccess) {
 		fprintf(stderr, "[bwamem_hip] context creation failed: %s\n", hipGetErrorString(e));
 		bmh_ctx_destroy(ctx);
 		return BMH_E_NODEVICE;
@@ -219,6 +224,7 @@ int bmh_ctx_create(bmh_ctx_t **out, int device)
 	if (const char *m = getenv("BMH_EXT_MODE")) ctx->force_kernel = !strcmp(m, "lds") ? 1 : !strcmp(m, "reg") ? 2 : !strcmp(m, "grp") ? 3 : !strcmp(m, "lanex4") ? 4 : 0;
 	if (const char *m = getenv("BMH_GLB_MODE")) ctx->glb_mode = !strcmp(m, "wave") ? 1 : 0;
 	if (const char *m = getenv("BMH_SW_MODE")) ctx->sw_mode = !strcmp(m, "generic") ? 1 : 0;
+	if (const char *m = getenv("BMH_SW_WAVE")) ctx->sw_wave = atoi(m) != 0;
 	if (const char *m = getenv("BMH_GRID_MULT")) ctx->grid_mult = atoi(m) > 0 ? atoi(m) : 1;
 	if (const char *m = getenv("BMH_EXT_SCHED")) ctx->ext_sched = atoi(m) >= 0 && atoi(m) <= 4 ? atoi(m) : -1;
 	*out = ctx;
@@ -232,7 +238,7 @@ int bmh_ctx_destroy(bmh_ctx_t *ctx)
 {
 	if (!ctx) return BMH_OK;
 	(void)hipSetDevice(ctx->device);
-	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+	if (ctx->stream) (void)stream_wait(ctx, ctx->stream);
 	free_buf(ctx->d_pool), free_buf(ctx->d_tasks), free_buf(ctx->d_res), free_buf(ctx->d_order);
 	free_buf(ctx->d_cigar), free_buf(ctx->d_scratch), free_buf(ctx->d_bins), free_buf(ctx->d_zslab), free_buf(ctx->d_sw), free_buf(ctx->d_swrm);
 	free_buf(ctx->d_seedws);
@@ -261,6 +267,7 @@ int bmh_ctx_destroy(bmh_ctx_t *ctx)
 	if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
 	if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
 	if (ctx->ev_join2) (void)hipEventDestroy(ctx->ev_join2);
+	if (ctx->ev_wait) (void)hipEventDestroy(ctx->ev_wait);
 	if (ctx->aux2_stream) (void)hipStreamDestroy(ctx->aux2_stream);
 	if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
 	delete ctx;
@@ -375,7 +382,7 @@ int bmh_ctx_sync(bmh_ctx_t *ctx)
 {
 	if (!ctx) return BMH_E_ARG;
 	BMH_HIP(ctx, hipSetDevice(ctx->device));
-	BMH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	BMH_HIP(ctx, stream_wait(ctx, ctx->stream));
 	return fetch_err(ctx);
 }
 
@@ -514,7 +521,7 @@ int bmh_upload_pool(bmh_ctx_t *ctx, const uint8_t *pool, size_t bytes)
 	if ((rc = ensure(ctx, ctx->d_pool, bytes + 16))) return rc;
 	Stager st;
 	if ((rc = st.begin(ctx, bytes, 0)) || (rc = st.h2d(ctx->d_pool.p, pool, bytes))) return rc;
-	BMH_HIP(ctx, hipStreamSynchronize(ctx->stream)); // `pool` may be freed by the caller on return
+	BMH_HIP(ctx, stream_wait(ctx, ctx->stream)); // `pool` may be freed by the caller on return
 	ctx->pool_resident = true, ctx->pool_bytes = bytes;
 	return BMH_OK;
 }
@@ -546,7 +553,7 @@ int bmh_extend_batch_sharded(bmh_ctx_t *const *ctxs, int n_ctx, const uint8_t *p
 		if ((rc = validate_ext(c, t, m, pool_bytes, &qmax))) {
 			for (int h = 0; h < g; ++h) {
 				(void)hipSetDevice(ctxs[h]->device);
-				(void)hipStreamSynchronize(ctxs[h]->stream);
+				(void)stream_wait(ctxs[h], ctxs[h]->stream);
 			}
 			return rc;
 		}
@@ -567,7 +574,7 @@ int bmh_extend_batch_sharded(bmh_ctx_t *const *ctxs, int n_ctx, const uint8_t *p
 		if (rc) { // copies into the caller's `results` may be in flight on the devices already served: drain them first
 			for (int h = 0; h <= g; ++h) {
 				(void)hipSetDevice(ctxs[h]->device);
-				(void)hipStreamSynchronize(ctxs[h]->stream);
+				(void)stream_wait(ctxs[h], ctxs[h]->stream);
 			}
 			return rc;
 		}

@@ -31,6 +31,7 @@ struct bmh_ctx {
 	DevBuf d_zslab; // direction words of the lane-per-task global kernels, one slab per resident wave
 	int glb_mode = 0; // 0 lane-per-task global kernels, 1 one wave per task only (env BMH_GLB_MODE=wave)
 	int sw_mode = 0;  // 0 register kernels where they fit, 1 slab kernel only (env BMH_SW_MODE=generic)
+	int sw_wave = 1;  // batches of up to 32 k tasks: one wave per task (sw_wave.hip); env BMH_SW_WAVE=0 turns it off
 	DevBuf d_bins; // per-launch bin lists of the extension dispatcher: 4 counters + 4 x n task indices
 	int grid_mult = 1;    // env BMH_GRID_MULT: persistent grid = resident waves x this (tuning knob)
 	int ext_sched = -1;   // env BMH_EXT_SCHED: launch order / streams of the extension bins, -1 = by query length (see launch_extend)
@@ -54,6 +55,7 @@ struct bmh_ctx {
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 	hipStream_t aux2_stream = nullptr; // ... and the two short-query bins beside the 128-column one
 	hipEvent_t ev_join2 = nullptr;
+	hipEvent_t ev_wait = nullptr; // hipEventBlockingSync: what stream_wait() sleeps on in blocking mode
 	bool ev_bin_valid = false;
 	hipEvent_t ev_gbin[4] = {}; // boundaries of the three kernels of a global-alignment launch (64-slot, 128-slot, wave)
 	bool ev_gbin_valid = false;
@@ -99,6 +101,14 @@ struct GateGuard {
 };
 
 int set_hip_error(bmh_ctx *ctx, hipError_t e, const char *what);
+// every host wait for a stream goes through here (bmh_set_wait_mode)
+extern int g_wait_blocking;
+inline hipError_t stream_wait(bmh_ctx *ctx, hipStream_t s)
+{
+	if (!g_wait_blocking || !ctx->ev_wait) return hipStreamSynchronize(s);
+	const hipError_t e = hipEventRecord(ctx->ev_wait, s);
+	return e != hipSuccess ? e : hipEventSynchronize(ctx->ev_wait);
+}
 int ensure(bmh_ctx *ctx, DevBuf &b, size_t bytes);
 int ensure_host(bmh_ctx *ctx, DevBuf &b, size_t bytes); // same, pinned host memory
 
@@ -142,6 +152,9 @@ int launch_sw(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks,
 int launch_sw_lane(bmh_ctx *ctx, int b, bool corr, bool word, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks, int64_t n,
                    bmh_sw_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, uint16_t *d_rm, int rows_cap,
                    int grid, int pass2, uint32_t *d_next);
+bool sw_wave_fits(int64_t n, int qcap, int tcap);
+int launch_sw_wave(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks, int64_t n, bmh_sw_result_t *d_res, int max_cols,
+                   int tcap);
 int launch_sw_generic(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks, int64_t n,
                       bmh_sw_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, int qcap, int tcap);
 int launch_extend_lane(bmh_ctx *ctx, int c, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,

@@ -531,7 +531,7 @@ int bmh_sa_batch(bmh_ctx_t *ctx, const uint64_t *k, int64_t n, uint64_t *pos)
 		ctx->ev_valid = true;
 	}
 	BMH_HIP(ctx, hipMemcpyAsync(ctx->h_down.p, ctx->d_res.p, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
-	BMH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+	BMH_HIP(ctx, stream_wait(ctx, ctx->stream));
 	memcpy(pos, ctx->h_down.p, (size_t)n * 8);
 	return BMH_OK;
 }
@@ -632,7 +632,7 @@ int bmh_smem_batch(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const b
 			ctx->ev_valid = true;
 		}
 		BMH_HIP(ctx, hipMemcpyAsync(ctx->h_down.p, d, 16, hipMemcpyDeviceToHost, ctx->stream));
-		BMH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		BMH_HIP(ctx, stream_wait(ctx, ctx->stream));
 		memcpy(totals, ctx->h_down.p, 16);
 		ctx->smem_calls_per_base = std::max(ctx->smem_calls_per_base, (double)totals[0] / (double)std::max<size_t>(bytes, 1));
 		ctx->smem_intv_per_base = std::max(ctx->smem_intv_per_base, (double)totals[1] / (double)std::max<size_t>(bytes, 1));
@@ -648,7 +648,7 @@ int bmh_smem_batch(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const b
 				BMH_HIP(ctx, hipMemcpyAsync(h + b_calls, d + o_cr, n_calls * 4, hipMemcpyDeviceToHost, ctx->stream));
 			}
 			if (totals[1]) BMH_HIP(ctx, hipMemcpyAsync(h + b_calls + b_read, d + o_intv, b_intv, hipMemcpyDeviceToHost, ctx->stream));
-			BMH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+			BMH_HIP(ctx, stream_wait(ctx, ctx->stream));
 			break;
 		}
 		d_calls = std::max(d_calls, (size_t)totals[0] + 64), d_intv = std::max(d_intv, (size_t)totals[1] + 64);

@@ -36,4 +36,15 @@ __device__ __forceinline__ void sw_second_best(const uint16_t *rm, int stride, i
 	*score2 = s2, *te2 = t2;
 }
 
+// Tasks sw_wave_kernel takes when a batch goes its way (launch_sw): those whose striped byte or word arithmetic cannot
+// saturate -- the register kernels' condition (sw_dispatch.hip) -- and whose padded query fits max_cols columns.
+__device__ __forceinline__ bool sw_wave_takes(const DevParams &P, int qlen, uint32_t xtra, int max_cols)
+{
+	if (qlen < 1) return false;
+	const bool byte_mode = xtra & BMH_SW_XBYTE;
+	const int segs = byte_mode ? 16 : 8;
+	if ((qlen + segs - 1) / segs * segs > max_cols) return false;
+	return byte_mode ? qlen * P.max_mat + P.sw_shift < 255 : qlen * P.max_mat + P.sw_shift < 512;
+}
+
 } // namespace bmh

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(kSwSortThreads) void sw_hist_kernel(const bmh_sw_ta
                                                                  const bmh_sw_result_t *__restrict__ res, DevParams P,
                                                                  uint32_t *__restrict__ hist,
                                                                  uint16_t *__restrict__ binkey, int mode, int pass2,
-                                                                 const uint8_t *__restrict__ pool, int qfine)
+                                                                 const uint8_t *__restrict__ pool, int qfine, int wave_cols)
 {
 	__shared__ uint32_t lh[kSortBins * kSortKeysHost];
 	for (int t = threadIdx.x; t < kSortBins * kSortKeysHost; t += kSwSortThreads) lh[t] = 0;
@@ -55,7 +55,8 @@ __global__ __launch_bounds__(kSwSortThreads) void sw_hist_kernel(const bmh_sw_ta
 		int qlen = tasks[k].qlen, rows = (int)min(tasks[k].tlen, 0xffffu);
 		int bin = sw_bin_of(P, qlen, xtra, mode);
 		bool has_n = false;
-		if (!pass2 && bin < 2) { // an N anywhere in the query sends the task to the correcting instantiation
+		const bool done = wave_cols > 0 && sw_wave_takes(P, qlen, xtra, wave_cols); // sw_wave_kernel has been through the batch
+		if (!pass2 && bin < 2 && !done) { // an N anywhere in the query sends the task to the correcting instantiation
 			const uint64_t q0 = tasks[k].q_off;
 			const bool rev = tasks[k].flags & BMH_F_QREV;
 			for (int x = 0; x < qlen; ++x) has_n |= (rev ? pool[q0 - x] : pool[q0 + x]) > 3;
@@ -74,7 +75,8 @@ __global__ __launch_bounds__(kSwSortThreads) void sw_hist_kernel(const bmh_sw_ta
 		// apart and five are left for the row count, so that the lanes of a wave finish within 32 rows of one another
 		const int key = !sw_lane_bin(bin) ? 0 : (!pass2 && qfine >= 0) ? ((qlen - qfine) << 5) | min(rows >> 5, 31) : (min(qlen, 255) << 3) | min(rows >> 7, 7);
 		if (bin < 2 && has_n) bin += 3;
-		const int bk = bin * kSortKeysHost + key;
+		if (done) bin = 5;
+		const int bk = bin * kSortKeysHost + (done ? 0 : key);
 		binkey[k] = (uint16_t)bk;
 		atomicAdd(&lh[bk], 1u);
 	}
@@ -103,10 +105,15 @@ int launch_sw(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks,
 		hipLaunchKernelGGL(sw_caps_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 1024)), dim3(256), 0,
 		                   ctx->stream, d_tasks, (long long)n, caps);
 		BMH_HIP(ctx, hipMemcpyAsync(h, caps, 12, hipMemcpyDeviceToHost, ctx->stream));
-		BMH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+		BMH_HIP(ctx, stream_wait(ctx, ctx->stream));
 		qcap = h[0], tcap = h[1], qmin = 65535 - h[2];
 	}
 	const int qfine = (qmin >= 1 && qcap - qmin < 64) ? qmin : -1; // see sw_hist_kernel
+	// a batch that cannot fill the chip with one lane per task goes to one wave per task (sw_wave.hip): the register
+	// kernels' launches take as long as one lane's whole matrix, milliseconds however few the tasks.  What that kernel does
+	// not take (arithmetic that can saturate) still goes through the routing below, to sw_generic_kernel.
+	const bool wave = ctx->sw_mode == 0 && ctx->sw_wave && sw_wave_fits(n, qcap, tcap);
+	const int wave_cols = wave ? ((std::max(qcap, 1) + 15) / 16 * 16 <= 192 ? 192 : 320) : 0;
 	qcap = std::max(qcap, 1) + 16, tcap = std::max(tcap, 1);
 	if (ctx->params.o_del > 255 || ctx->params.e_del > 255 || ctx->params.o_ins > 255 || ctx->params.e_ins > 255) {
 		ctx->last_error = "the Smith-Waterman kernels need gap penalties below 256";
@@ -118,16 +125,21 @@ int launch_sw(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks,
 	long long cg = std::min<long long>((n + 1023) / 1024, 512);
 	// per-wave slab of row maxima for the second-best score (ksw.c:181-189): [block][row][lane] u16
 	const int grid = (int)std::min<long long>((n + 63) / 64, 2048 * ctx->grid_mult); // resident waves: 256 CUs x 4 SIMDs x 2
-	if ((rc = ensure(ctx, ctx->d_swrm, (size_t)grid * ((size_t)tcap * 128 + 2048)))) return rc; // + kSwTableBytes per wave
+	if (!wave && (rc = ensure(ctx, ctx->d_swrm, (size_t)grid * ((size_t)tcap * 128 + 2048)))) return rc; // + kSwTableBytes per wave
 	uint16_t *d_rm = (uint16_t *)ctx->d_swrm.p;
 	if (ctx->timing) BMH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-	for (int pass2 = 0; pass2 < 2; ++pass2) {
+	if (wave && (rc = launch_sw_wave(ctx, d_pool, d_tasks, n, d_res, wave_cols, tcap))) return rc;
+	for (int pass2 = 0; pass2 < (wave ? 1 : 2); ++pass2) { // (sw_generic_kernel runs its second pass itself)
 		if ((rc = sort_tasks_begin(ctx, n, &counts, &lists))) return rc;
 		uint32_t *hist = counts + 16;
 		uint16_t *binkey = (uint16_t *)(hist + (size_t)kSortBins * kSortKeysHost);
 		hipLaunchKernelGGL(sw_hist_kernel, dim3((unsigned)cg), dim3(kSwSortThreads), 0, ctx->stream, d_tasks, (long long)n,
-		                   d_res, ctx->dev, hist, binkey, mode, pass2, d_pool, qfine);
+		                   d_res, ctx->dev, hist, binkey, mode, pass2, d_pool, qfine, wave_cols);
 		if ((rc = sort_tasks_finish(ctx, n, nullptr, (unsigned)cg))) return rc;
+		if (wave) { // every bin but sw_generic_kernel's is empty
+			if ((rc = launch_sw_generic(ctx, d_pool, d_tasks, n, d_res, lists + 2 * N, counts + 2, qcap, tcap))) return rc;
+			break;
+		}
 		// (counts[b] = size of bin b, counts[8 + b] = its chunk cursor; longest columns first)
 		if ((rc = launch_sw_lane(ctx, 128, true, true, d_pool, d_tasks, n, d_res, lists + 7 * N, counts + 7, d_rm, tcap, grid, pass2, counts + 15))) return rc;
 		if (qcap > 160 + 16 && (rc = launch_sw_lane(ctx, 128, true, false, d_pool, d_tasks, n, d_res, lists + 6 * N, counts + 6, d_rm, tcap, grid, pass2, counts + 14))) return rc;

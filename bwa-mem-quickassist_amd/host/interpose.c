@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <malloc.h>
 
 #include <pthread.h>
 #include <semaphore.h>
@@ -25,7 +26,7 @@
 #include "../../include/bwamem_hip.h"
 #include "tls_ctx.h"
 
-/* At most this many host threads are inside a GPU batch call at a time ($BMH_GPU_CONCURRENCY, default 8): the calls of
+/* At most this many host threads are inside a GPU batch call at a time ($BMH_GPU_CONCURRENCY, default 12): the calls of
  * more threads than that only queue up behind one another on the device, and their workspace (re)allocations, which
  * synchronise the whole device, collide.  The host work around the calls (chaining, folding) is not limited. */
 static sem_t g_gpu_sem;
@@ -33,7 +34,7 @@ static pthread_once_t g_gpu_once = PTHREAD_ONCE_INIT;
 static int gpu_concurrency(void)
 {
 	const char *e = getenv("BMH_GPU_CONCURRENCY");
-	return e && atoi(e) > 0 ? atoi(e) : 8;
+	return e && atoi(e) > 0 ? atoi(e) : 12;
 }
 static void gpu_sem_init(void) { sem_init(&g_gpu_sem, 0, (unsigned)gpu_concurrency()); }
 static void gpu_enter(void)
@@ -67,12 +68,28 @@ __attribute__((constructor)) static void qa_shim_loaded(void)
 {
 	const char *e = getenv("BMH_PREWARM"), *pl = getenv("LD_PRELOAD");
 	pthread_t t;
-	/* The HIP runtime multiplexes all streams of a process onto 4 hardware queues by default; with 8 host threads inside
-	 * batch calls (16 streams) a thread's small extension kernels then wait behind another thread's 10-20 ms seeding
-	 * kernel that happens to share its queue (measured: phase 1 of a 400 k-read chunk 0.48 s -> 0.21 s with 8 queues).
+	/* The HIP runtime multiplexes all streams of a process onto 4 hardware queues by default; with many host threads inside
+	 * batch calls a thread's small extension kernels then wait behind another thread's seeding or Smith-Waterman kernel
+	 * of milliseconds that happens to share its queue (measured, steady-state chunk of 1.07 M reads at 16 threads: 0.48 s
+	 * with 4 queues, 0.35 s with 8, 0.28 s with 16 and 12 threads admitted to the GPU at a time; 24 is slower again).
 	 * Must be in the environment before the runtime initialises; a value the user has set is left alone. */
-	setenv("GPU_MAX_HW_QUEUES", "8", 0);
+	setenv("GPU_MAX_HW_QUEUES", "16", 0);
 	bmh_set_device_gate(gpu_enter, gpu_leave); /* the library holds a GPU place for its device sections only */
+	/* The drivers allocate and free a few buffers of megabytes per batch on every thread: keep that memory in the heaps
+	 * instead of handing it back to the kernel and faulting it in again each time (mprotect/munmap/page faults were ~8 % of
+	 * the CPU time of a chunk). */
+	{
+		const char *m = getenv("BMH_MALLOPT");
+		const int bits = m ? atoi(m) : 3; /* (a larger M_TOP_PAD, bit 4, measured much slower) */
+		if (bits & 1) mallopt(M_TRIM_THRESHOLD, 1 << 30);
+		if (bits & 2) mallopt(M_MMAP_THRESHOLD, 32 << 20);
+		if (bits & 4) mallopt(M_TOP_PAD, 16 << 20);
+	}
+	{ /* as many host threads as cores drive the library here: a thread waiting for the GPU sleeps instead of spinning
+	   * (BMH_WAIT=spin restores the library's default) */
+		const char *w = getenv("BMH_WAIT");
+		bmh_set_wait_mode(!(w && !strcmp(w, "spin")));
+	}
 	if (e && e[0] == '0') return;
 	if (!pl || !strstr(pl, "libbwamem_hip_dropin")) return; /* only when preloaded into a host program, not when merely dlopen()ed */
 	{ /* ... and only into `<prog> mem ...`: index building, usage errors etc. never touch the GPU */
@@ -411,6 +428,15 @@ static void qa_sam_slice(void *data, int k, int tid)
 	__sync_fetch_and_add(&g_sam_us[0], (long long)((t1 - t0) * 1e6)), __sync_fetch_and_add(&g_sam_us[1], (long long)((t2 - t1) * 1e6));
 }
 
+/* host threads of a phase: the program's -t unless the named variable says otherwise (a thread that waits for the GPU
+ * sleeps, so more threads than cores can pay) */
+static int qa_threads(const char *var, int dflt)
+{
+	const char *e = getenv(var);
+	const int v = e ? atoi(e) : 0;
+	return v > 0 ? v : dflt > 0 ? dflt : 1;
+}
+
 void mem_process_seqs(const ref_mem_opt_t *opt, const void *bwt, const ref_bntseq_head_t *bns, const uint8_t *pac,
                       int64_t n_processed, int n, ref_bseq1_t *seqs, const bmh_pestat_t *pes0)
 {
@@ -423,12 +449,12 @@ void mem_process_seqs(const ref_mem_opt_t *opt, const void *bwt, const ref_bntse
 	bmh_read_t *reads;
 	qa_slice_job_t J;
 	double ctime, rtime, t_[4], t_pes;
-	int i;
+	int i, nt2;
 	ctime = cputime(), rtime = realtime();
 	t_[0] = rtime;
 	w.opt = opt, w.bwt = bwt, w.bns = bns, w.pac = pac, w.seqs = seqs;
 	w.regs = (bmh_alnreg_v *)malloc((size_t)n * sizeof(bmh_alnreg_v));
-	kt_for_batch(opt->n_threads, qa_worker1_batched, &w, n, opt->batch_size); /* bwamem.c:1313 */
+	kt_for_batch(qa_threads("BMH_P1_THREADS", opt->n_threads), qa_worker1_batched, &w, n, opt->batch_size); /* bwamem.c:1313 */
 	t_[1] = realtime();
 	memset(&so, 0, sizeof(so)); /* the fields of mem_opt_t phase 2 reads */
 	so.a = opt->a, so.b = opt->b, so.o_del = opt->o_del, so.e_del = opt->e_del, so.o_ins = opt->o_ins, so.e_ins = opt->e_ins;
@@ -454,16 +480,17 @@ void mem_process_seqs(const ref_mem_opt_t *opt, const void *bwt, const ref_bntse
 	}
 	J.opt = opt, J.bns = bns, J.pac = pac, J.n = n, J.seqs = seqs, J.regs = w.regs, J.reads = reads, J.params = &p, J.pes = pes;
 	J.sopt = &so, J.n_processed = n_processed;
-	J.n_slices = opt->n_threads > 0 ? opt->n_threads : 1;
+	nt2 = qa_threads("BMH_P2_THREADS", opt->n_threads);
+	J.n_slices = qa_threads("BMH_P2_SLICES", nt2);
 	if (rescue) { /* the whole chunk's mate rescue (the block of mem_sam_pe at bwamem_pair.c:251-263), one bmh_matesw_batch per slice */
 		g_msw_calls = g_msw_rounds_max = g_msw_bytes = 0;
-		kt_for(opt->n_threads, qa_matesw_slice, &J, J.n_slices);
+		kt_for(nt2, qa_matesw_slice, &J, J.n_slices);
 		if (getenv("BMH_VERBOSE"))
 			fprintf(stderr, "[bwamem_hip] mate rescue: %d pairs, %lld ksw_align2 calls in %lld GPU rounds, %lld pool bytes\n", n >> 1,
 			        g_msw_calls, g_msw_rounds_max, g_msw_bytes);
 	}
 	t_[2] = realtime();
-	kt_for(opt->n_threads, qa_sam_slice, &J, J.n_slices); /* bwamem.c:1318-1319 */
+	kt_for(nt2, qa_sam_slice, &J, J.n_slices); /* bwamem.c:1318-1319 */
 	t_[3] = realtime();
 	free(reads);
 	if (getenv("BMH_VERBOSE")) {

@@ -45,7 +45,7 @@ static int pool_device(int nth)
 static void pool_reserve(bmh_ctx_t *ctx)
 {
 	const char *e = getenv("BMH_RESERVE_MB");
-	const size_t mb = e ? (size_t)atoi(e) : 64;
+	const size_t mb = e ? (size_t)atoi(e) : 16;
 	if (mb == 0) return;
 	(void)bmh_ctx_reserve_staging(ctx, mb << 20, mb << 20);
 	(void)bmh_ctx_reserve_device(ctx, mb << 20, (int64_t)(mb << 10) * 2, (mb << 20) / 8);

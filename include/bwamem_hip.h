@@ -135,6 +135,12 @@ int bmh_ctx_set_qcap(bmh_ctx_t *ctx, int max_qlen);
  * the L3 drivers around those sections (state machines, band logic, text) runs on all threads.  NULL, NULL removes it. */
 typedef void (*bmh_gate_fn)(void);
 int bmh_set_device_gate(bmh_gate_fn enter, bmh_gate_fn leave);
+/* How the host-buffer entry points wait for the GPU, process-wide.  0 (default): spinning on the completion signal --
+ * the shortest latency, one core per waiting thread.  1: sleeping until the GPU's interrupt (an event created with
+ * hipEventBlockingSync, and hipDeviceScheduleBlockingSync on the devices of contexts created afterwards) -- for programs
+ * with as many or more runnable host threads than cores: measured on the preload shim at 16 threads on 16 cores, a third
+ * of all CPU time was spent spinning inside these waits. */
+void bmh_set_wait_mode(int blocking);
 
 /* ---- L2, host buffers: H2D copy, launch, D2H copy, synchronous on return. */
 int bmh_extend_batch(bmh_ctx_t *ctx, const uint8_t *seqpool, size_t pool_bytes,

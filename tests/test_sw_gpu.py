@@ -12,15 +12,25 @@ from test_kernel_families_gpu import _ctx_with
 pytestmark = pytest.mark.gpu
 
 
+# the three kernel families behind bmh_sw_batch: one wave per task (what batches of up to 32 k tasks get), one lane per task
+# (the register kernels; forced here by turning the wave kernel off), the slab kernel for everything
+MODES = ["wave", "lane", "generic"]
+
+
+def _sw_ctx(mode):
+    return _ctx_with({"wave": {"BMH_SW_MODE": "default"}, "lane": {"BMH_SW_MODE": "default", "BMH_SW_WAVE": "0"},
+                      "generic": {"BMH_SW_MODE": "generic"}}[mode])
+
+
 def _cmp(got, want, tasks, what):
     for f in kswlib.SW_FIELDS:
         bad = np.nonzero(got[f] != want[f])[0]
         assert len(bad) == 0, f"{what}, {f}: task {tasks[bad[0]]} gpu={got[bad[0]]} want={want[bad[0]]}"
 
 
-@pytest.mark.parametrize("mode", ["default", "generic"])
+@pytest.mark.parametrize("mode", MODES)
 def test_sw_matches_reference_fixture(mode):
-    ctx = _ctx_with({"BMH_SW_MODE": mode})
+    ctx = _sw_ctx(mode)
     g = kswlib.load_golden("sw_golden.npz")
     pool, tasks, exp, grp, params = g["pool"], g["tasks"], g["expect"], g["group"], g["params"]
     for k in range(len(params)):
@@ -30,9 +40,9 @@ def test_sw_matches_reference_fixture(mode):
     ctx.close()
 
 
-@pytest.mark.parametrize("mode", ["default", "generic"])
+@pytest.mark.parametrize("mode", MODES)
 def test_sw_matches_oracle_materescue_and_fuzz(mode):
-    ctx = _ctx_with({"BMH_SW_MODE": mode})
+    ctx = _sw_ctx(mode)
     rng = np.random.default_rng(121)
     p = kswlib.make_params()
     ctx.set_params(p)
@@ -51,11 +61,11 @@ def test_sw_matches_oracle_materescue_and_fuzz(mode):
     ctx.close()
 
 
-@pytest.mark.parametrize("mode", ["default", "generic"])
+@pytest.mark.parametrize("mode", MODES)
 def test_sw_250bp_class(mode):
     """Queries of 161-256 columns: byte mode below 250 columns, WORD mode (ksw_i16, 8 segments) from there on -- what
     mem_matesw sends for 2 x 250 bp reads (reference bwamem_pair.c:147).  Both go to the 256-column register kernels."""
-    ctx = _ctx_with({"BMH_SW_MODE": mode})
+    ctx = _sw_ctx(mode)
     rng = np.random.default_rng(1250)
     for p, lens in ((kswlib.make_params(), (161, 256)), (kswlib.make_params(), (250, 250)), (kswlib.make_params(), (249, 251)),
                     (kswlib.make_params(a=2, b=5), (100, 256)), (kswlib.make_params(o_del=4, e_del=2, o_ins=6, e_ins=1), (200, 256))):
