@@ -449,7 +449,9 @@ def main():
         for k in kernels:
             k["avg_launch_ms"] = k["ms"] / k["launches"]
             k["GBps"] = k["algorithmic_bytes"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else None
-        dom = max(kernels, key=lambda k: k["ms"])
+        # the dominant kernel of the roofline object is ONE kernel (a row of the rocprofv3 summary in profiles/), not a round of the
+        # fused extension, which is three lane kernels and a record kernel: the largest of the entries that are a single kernel
+        dom = max((k for k in kernels if k["kernel"].startswith(("global_lane_kernel", "global_kernel"))), key=lambda k: k["ms"])
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         traffic_src = None

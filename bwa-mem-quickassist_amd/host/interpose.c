@@ -454,7 +454,21 @@ void mem_process_seqs(const ref_mem_opt_t *opt, const void *bwt, const ref_bntse
 	t_[0] = rtime;
 	w.opt = opt, w.bwt = bwt, w.bns = bns, w.pac = pac, w.seqs = seqs;
 	w.regs = (bmh_alnreg_v *)malloc((size_t)n * sizeof(bmh_alnreg_v));
-	kt_for_batch(qa_threads("BMH_P1_THREADS", opt->n_threads), qa_worker1_batched, &w, n, opt->batch_size); /* bwamem.c:1313 */
+	{ /* bwamem.c:1313, with the batch size evened out: -b 65536 cuts a chunk of 1 066 668 reads into 16 batches and a 17th
+	   * of 18 092 that one thread runs alone after all others are done; the same reads in 16 batches of 66 667 are not a
+	   * read slower per batch.  As many batches as -b asks for, rounded to a multiple of the thread count, at least 4 096
+	   * reads each.  BMH_BATCH_EXACT=1 keeps -b to the read. */
+		const int nt = qa_threads("BMH_P1_THREADS", opt->n_threads);
+		int b = opt->batch_size > 0 ? opt->batch_size : 1;
+		if (!getenv("BMH_BATCH_EXACT") && n > 0) {
+			int64_t rounds = ((int64_t)n + (int64_t)b * nt / 2) / ((int64_t)b * nt), nb;
+			if (rounds < 1) rounds = 1;
+			nb = rounds * nt;
+			if ((int64_t)n / nb < 4096) nb = ((int64_t)n + 4095) / 4096;
+			b = (int)(((int64_t)n + nb - 1) / nb);
+		}
+		kt_for_batch(nt, qa_worker1_batched, &w, n, b);
+	}
 	t_[1] = realtime();
 	memset(&so, 0, sizeof(so)); /* the fields of mem_opt_t phase 2 reads */
 	so.a = opt->a, so.b = opt->b, so.o_del = opt->o_del, so.e_del = opt->e_del, so.o_ins = opt->o_ins, so.e_ins = opt->e_ins;
