@@ -46,7 +46,9 @@ for k in sorted(acc):
         hi = (2 * means["FETCH_SIZE"] + means["WRITE_SIZE"]) * 1024
         print(f"\nHBM bytes per launch: {lo:.4g} (raw FETCH+WRITE) .. {hi:.4g} (FETCH doubled)\n")
         traffic[k] = {"hbm_bytes_per_launch": lo, "hbm_bytes_per_launch_fetch_x2": hi,
-                      "FETCH_SIZE_KiB": means["FETCH_SIZE"], "WRITE_SIZE_KiB": means["WRITE_SIZE"]}
+                      "FETCH_SIZE_KiB": means["FETCH_SIZE"], "WRITE_SIZE_KiB": means["WRITE_SIZE"],
+                      "valu_insts_per_launch": means.get("SQ_INSTS_VALU"), "salu_insts_per_launch": means.get("SQ_INSTS_SALU"),
+                      "waves_per_launch": means.get("SQ_WAVES")}
     print()
 if tj:
     commit = os.popen("git -C %s rev-parse --short HEAD 2>/dev/null" % os.path.dirname(os.path.abspath(__file__))).read().strip()
