@@ -108,14 +108,20 @@ def pipeline_baseline(n_reads, genome_bp, threads, batch=8192, noisy=0.3, dut=Tr
         err = p.stderr.decode(errors="replace")
         if p.returncode != 0:
             return {"error": err[-400:]}
-        reads = real = 0
+        reads = real = cpu_s = 0
+        per_chunk = []
         for m in re.finditer(r"Processed (\d+) reads in ([\d.]+) CPU sec, ([\d.]+) real sec", err):
             reads += int(m.group(1))
+            cpu_s += float(m.group(2))
             real += float(m.group(3))
+            per_chunk.append((int(m.group(1)), float(m.group(3))))
+        later = per_chunk[1:]  # the first chunk of a run also pays for contexts, workspaces and heaps growing to size
         chunks = [l.split("] ", 1)[1] for l in err.splitlines() if l.startswith("[bwamem_hip] chunk of")]
         tail = [l.split("] ", 1)[1] for l in err.splitlines() if l.startswith(("[bwamem_hip] phase", "[bwamem_hip] seeding batch", "[bwamem_hip] mate rescue"))]
         drv = [l.split("] ", 1)[1] for l in err.splitlines() if l.startswith(("[bwamem_hip] bmh_sam_batch", "[bwamem_hip] bmh_reg2cigar_batch", "[bwamem_hip] bmh_chain2aln_batch"))]
-        return {"reads": reads, "real_s": real, "reads_per_s": reads / real if real else None, "wall_s": time.time() - t0,
+        return {"reads": reads, "real_s": real, "reads_per_s": reads / real if real else None, "wall_s": time.time() - t0, "cpu_s": cpu_s,
+                "chunk_real_s": [c[1] for c in per_chunk],
+                "reads_per_s_after_first_chunk": (sum(c[0] for c in later) / sum(c[1] for c in later)) if later and sum(c[1] for c in later) > 0 else None,
                 "chunks": chunks[:8] if preload else None, "thread_seconds": tail[-5:] if preload else None, "driver_trace": drv[-48:-40] + drv[-6:] if drv else None}
 
     if dut:
@@ -131,6 +137,7 @@ def pipeline_baseline(n_reads, genome_bp, threads, batch=8192, noisy=0.3, dut=Tr
                      f"reads/s from the reference's own per-chunk 'Processed ... real sec' lines",
            "dut_value": d.get("reads_per_s"), "dut": "same binary, LD_PRELOAD=libbwamem_hip_dropin.so, BMH_KSW_DROPIN=1, same -t",
            "dut_over_ref": (d["reads_per_s"] / r["reads_per_s"]) if r.get("reads_per_s") and d.get("reads_per_s") else None,
+           "dut_value_after_first_chunk": d.get("reads_per_s_after_first_chunk"), "ref_cpu_s": r.get("cpu_s"), "dut_cpu_s": d.get("cpu_s"),
            "sam_identical": same, "ref": r, "dut_detail": d, "index_s": t_index}
     for f in os.listdir(tmp):
         os.unlink(os.path.join(tmp, f))
@@ -175,7 +182,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the oracle-port CPU baseline (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline-baseline", action="store_true")
-    ap.add_argument("--pipeline-reads", type=int, default=3_200_000, help="reads of the whole-pipeline baseline (three chunks of bwa's at 16 threads)")
+    ap.add_argument("--pipeline-reads", type=int, default=6_400_000, help="reads of the whole-pipeline baseline (six chunks of bwa's at 16 threads)")
     ap.add_argument("--pipeline-batch", type=int, default=32768, help="the fork's -b: reads per phase-1 batch")
     ap.add_argument("--pipeline-genome", type=int, default=4_600_000)
     args, rest = ap.parse_known_args()

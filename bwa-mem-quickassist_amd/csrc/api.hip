@@ -184,7 +184,9 @@ int bmh_ctx_create(bmh_ctx_t **out, int device)
 	if (!ctx) return BMH_E_NOMEM;
 	ctx->device = device;
 	hipError_t e;
-	if ((e = hipSetDevice(device)) == hipSuccess && g_wait_blocking) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync); // (also covers hipMemcpy / hipFree)
+	if ((e = hipSetDevice(device)) == hipSuccess && g_wait_blocking) { // (also covers hipMemcpy / hipFree; refused on an active device by some runtimes: not an error)
+		if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError();
+	}
 	if (e != hipSuccess || (e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess ||
 	    (e = hipMalloc((void **)&ctx->d_err, sizeof(int))) != hipSuccess || (e = hipMemset(ctx->d_err, 0, sizeof(int))) != hipSuccess ||
 	    (e = hipHostMalloc((void **)&ctx->h_err, sizeof(int), hipHostMallocDefault)) != hipSuccess ||
