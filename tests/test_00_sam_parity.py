@@ -95,7 +95,7 @@ def test_se_sam_identical(genome, extra):
     fq = os.path.join(tmp, "se.fq")
     reflib.write_fastq(fq, reads)
     ref_sam = _run(fa, [fq], os.path.join(tmp, "ref.sam"), extra, False)
-    dut_sam = _run(fa, [fq], os.path.join(tmp, "dut.sam"), extra, True)
+    dut_sam = _run(fa, [fq], os.path.join(tmp, "dut.sam"), extra, True, {"BMH_BATCH_EXACT": "1"})  # batches of exactly -b reads
     assert len(ref_sam) > len(reads)
     assert ref_sam == dut_sam
     # phase 2 (primary marking, global alignments as GPU batches, SAM text) was the library's own bmh_sam_batch, not the
@@ -115,9 +115,11 @@ def test_pe_sam_identical(genome):
     reflib.write_fastq(f2, r2, "p")
     extra = ["-t", "4", "-b", "400"]
     ref_sam = _run(fa, [f1, f2], os.path.join(tmp, "ref_pe.sam"), extra, False)
-    dut_sam = _run(fa, [f1, f2], os.path.join(tmp, "dut_pe.sam"), extra, True)
+    dut_sam = _run(fa, [f1, f2], os.path.join(tmp, "dut_pe.sam"), extra, True, {"BMH_BATCH_EXACT": "1"})
     assert len(ref_sam) >= 2400
     assert ref_sam == dut_sam
+    # ... and with the batch size evened out over the chunk (the shim's default) and GPU waits that spin
+    assert ref_sam == _run(fa, [f1, f2], os.path.join(tmp, "dut_pe2.sam"), extra, True, {"BMH_WAIT": "spin"})
 
 
 def test_pe_mate_rescue_sam_identical(genome):
@@ -142,6 +144,34 @@ def test_pe_mate_rescue_sam_identical(genome):
     m = re.findall(r"mate rescue: (\d+) pairs, (\d+) ksw_align2 calls in (\d+) GPU rounds, (\d+) pool bytes", _run.last_stderr)
     assert m and sum(int(x[1]) for x in m) > 100 and all(int(x[2]) <= 12 for x in m)
     assert all(int(x[3]) <= int(x[0]) * 2 * 151 + 64 for x in m), "with the reference resident only the reads are shipped"
+
+
+def test_pe_250bp_mate_rescue_sam_identical(genome):
+    """2 x 250 bp: mem_matesw calls ksw_align2 in WORD mode (l_ms * a >= 250, bwamem_pair.c:147) -- on small batches the
+    320-column one-wave-per-task kernel, with BMH_SW_WAVE=0 the 256-column register kernels."""
+    rng, tmp, fa, ref = genome
+    r1, r2 = [], []
+    for _ in range(700):
+        ins = int(rng.integers(400, 700))
+        pos = int(rng.integers(0, len(ref) - ins - 60))
+        frag = ref[pos:pos + ins + 40]
+        a = kswgen.mutate(rng, frag[:280], 0.02, 0.0025, 0.0025, 1)[:250]
+        b = kswgen.mutate(rng, frag[ins - 250:ins + 30], 0.02, 0.004, 0.004, 2)[:250].copy()
+        if rng.random() < 0.5:  # a mismatch every 15 bases: no 19-mer seed anywhere, yet a local alignment of 170+ for mem_matesw
+            at = np.arange(int(rng.integers(0, 15)), 250, 15)
+            b[at] = (b[at] + rng.integers(1, 4, len(at))) & 3
+        r1.append(a.copy()), r2.append((3 - b[::-1]).astype(np.uint8))
+    f1, f2 = os.path.join(tmp, "l250_1.fq"), os.path.join(tmp, "l250_2.fq")
+    reflib.write_fastq(f1, r1, "w")
+    reflib.write_fastq(f2, r2, "w")
+    extra = ["-t", "4", "-b", "200"]
+    ref_sam = _run(fa, [f1, f2], os.path.join(tmp, "ref_250.sam"), extra, False)
+    assert len(ref_sam) >= 1400
+    assert ref_sam == _run(fa, [f1, f2], os.path.join(tmp, "dut_250.sam"), extra, True)
+    import re
+    m = re.findall(r"mate rescue: (\d+) pairs, (\d+) ksw_align2 calls", _run.last_stderr)
+    assert m and sum(int(x[1]) for x in m) > 100
+    assert ref_sam == _run(fa, [f1, f2], os.path.join(tmp, "dut_250l.sam"), extra, True, {"BMH_SW_WAVE": "0"})
 
 
 def test_multi_contig_reference_sam_identical():
