@@ -194,7 +194,6 @@ int bmh_ctx_create(bmh_ctx_t **out, int device)
 	    (e = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking)) != hipSuccess ||
 	    (e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)) != hipSuccess ||
 	    (e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming)) != hipSuccess ||
-	    (e = hipStreamCreateWithFlags(&ctx->aux2_stream, hipStreamNonBlocking)) != hipSuccess ||
 	    (e = hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming)) != hipSuccess ||
 	    (e = hipEventCreateWithFlags(&ctx->ev_wait, hipEventDisableTiming | hipEventBlockingSync)) != hipSuccess) {
 		fprintf(stderr, "[bwamem_hip] context creation failed: %s\n", hipGetErrorString(e));

@@ -249,7 +249,10 @@ int launch_extend(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_t
 	// are the critical path there (17.8 against 16.8 ms), so they keep the second stream to themselves.
 	const int sched = ctx->ext_sched >= 0 ? ctx->ext_sched : qmax <= 160 ? 2 : 1;
 	const int *order = orders[sched];
-	if (sched == 3) BMH_HIP(ctx, hipStreamWaitEvent(ctx->aux2_stream, ctx->ev_fork, 0));
+	if (sched == 3) { // (an A/B knob: its stream is made when first asked for -- a stream costs 2.7 ms to create)
+		if (!ctx->aux2_stream) BMH_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux2_stream, hipStreamNonBlocking));
+		BMH_HIP(ctx, hipStreamWaitEvent(ctx->aux2_stream, ctx->ev_fork, 0));
+	}
 	for (int k = 0; k < kExtBins; ++k) {
 		const int b = order[k];
 		ctx->stream = b >= 3 ? ctx->aux_stream : b < 2 && (sched == 2 || sched == 4) ? ctx->aux_stream : b < 2 && sched == 3 ? ctx->aux2_stream : main_s; // the launchers enqueue on ctx->stream

@@ -45,12 +45,15 @@ static void gpu_enter(void)
 static void gpu_leave(void) { sem_post(&g_gpu_sem); }
 
 /* When the shim is loaded: create the contexts the run will use in the background, while the host program parses its
- * arguments and loads its index ($BMH_PREWARM=0 turns this off). */
+ * arguments and loads its index ($BMH_PREWARM=0 turns this off, =N creates N; default: the host program's -t). */
+static int g_prewarm_n = 16; /* contexts to create ahead: one per host thread of the widest phase (a thread holds one while it is inside a driver call) */
+extern double cputime(void), realtime(void); /* the host program's (utils.c) */
+static double g_t_loaded; /* realtime() when the shim was loaded */
 static void *prewarm_thread(void *arg)
 {
-	const char *e = getenv("BMH_GPU_CONCURRENCY");
 	(void)arg;
-	bmh_pool_prewarm(e && atoi(e) > 0 ? 2 * atoi(e) : 16); /* every host thread holds a context while it is inside a driver call */
+	bmh_pool_prewarm(g_prewarm_n); /* (several threads creating contexts side by side are no faster: measured) */
+	if (getenv("BMH_VERBOSE")) fprintf(stderr, "[bwamem_hip] %d contexts ready %.3f s after the shim was loaded\n", g_prewarm_n, realtime() - g_t_loaded);
 	return 0;
 }
 /* A run shorter than the pre-warming (a few hundred reads) must not reach the runtime's teardown with that thread still
@@ -103,7 +106,22 @@ __attribute__((constructor)) static void qa_shim_loaded(void)
 		for (i = first_len + 1; i < n; i += strlen(buf + i) + 1)
 			if (!strcmp(buf + i, "mem")) { is_mem = 1; break; }
 		if (!is_mem) return;
+		for (; i < n; i += strlen(buf + i) + 1) /* its -t, as `-t N` or `-tN` */
+			if (buf[i] == '-' && buf[i + 1] == 't') {
+				const char *v = buf[i + 2] ? buf + i + 2 : (i + 3 < n ? buf + i + 3 : "");
+				if (atoi(v) > 0) g_prewarm_n = atoi(v);
+			}
+		{ /* phase 2 runs -t * 3/2 threads; $BMH_P1_THREADS / $BMH_P2_THREADS override the phases' thread counts; $BMH_PREWARM=N: N */
+			const char *v[3] = {getenv("BMH_P1_THREADS"), getenv("BMH_P2_THREADS"), e};
+			int k;
+			g_prewarm_n += g_prewarm_n / 2;
+			for (k = 0; k < 2; ++k)
+				if (v[k] && atoi(v[k]) > g_prewarm_n) g_prewarm_n = atoi(v[k]);
+			if (v[2] && atoi(v[2]) > 0) g_prewarm_n = atoi(v[2]);
+			if (g_prewarm_n > 128) g_prewarm_n = 128;
+		}
 	}
+	g_t_loaded = realtime();
 	if (pthread_create(&t, 0, prewarm_thread, 0) == 0) {
 		g_prewarm = t, g_prewarm_on = 1;
 		atexit(qa_shim_exit); /* registered after the HIP runtime's own handlers, so it runs before them */
@@ -126,7 +144,6 @@ typedef struct { int l_seq; char *name, *comment, *seq, *qual, *sam; } ref_bseq1
 
 /* what this shim still takes from the host program: its base-code table and its clocks (bntseq.c, utils.c) */
 extern unsigned char nst_nt4_table[256];
-extern double cputime(void), realtime(void);
 static double stage_now(void) /* the clock of the BMH_VERBOSE thread-second sums: wall time, or with BMH_TRACE_CPU the thread's CPU time */
 {
 	static int cpu = -1;
@@ -452,6 +469,8 @@ void mem_process_seqs(const ref_mem_opt_t *opt, const void *bwt, const ref_bntse
 	int i, nt2;
 	ctime = cputime(), rtime = realtime();
 	t_[0] = rtime;
+	if (n_processed == 0 && g_t_loaded > 0 && getenv("BMH_VERBOSE"))
+		fprintf(stderr, "[bwamem_hip] the first chunk starts %.3f s after the shim was loaded\n", rtime - g_t_loaded);
 	w.opt = opt, w.bwt = bwt, w.bns = bns, w.pac = pac, w.seqs = seqs;
 	w.regs = (bmh_alnreg_v *)malloc((size_t)n * sizeof(bmh_alnreg_v));
 	{ /* bwamem.c:1313, with the batch size evened out: -b 65536 cuts a chunk of 1 066 668 reads into 16 batches and a 17th
@@ -494,7 +513,10 @@ void mem_process_seqs(const ref_mem_opt_t *opt, const void *bwt, const ref_bntse
 	}
 	J.opt = opt, J.bns = bns, J.pac = pac, J.n = n, J.seqs = seqs, J.regs = w.regs, J.reads = reads, J.params = &p, J.pes = pes;
 	J.sopt = &so, J.n_processed = n_processed;
-	nt2 = qa_threads("BMH_P2_THREADS", opt->n_threads);
+	/* Phase 2 and mate rescue are host code with a GPU batch in the middle of every slice; half again as many threads as -t
+	 * keep the cores busy while some of them sleep on the GPU (measured at -t 16 on 16 cores: a chunk's rescue + phase 2
+	 * 0.105 -> 0.080 s; twice as many is no better; phase 1 does not gain). */
+	nt2 = qa_threads("BMH_P2_THREADS", opt->n_threads + opt->n_threads / 2);
 	J.n_slices = qa_threads("BMH_P2_SLICES", nt2);
 	if (rescue) { /* the whole chunk's mate rescue (the block of mem_sam_pe at bwamem_pair.c:251-263), one bmh_matesw_batch per slice */
 		g_msw_calls = g_msw_rounds_max = g_msw_bytes = 0;
