@@ -16,4 +16,4 @@ print(f"{sys.argv[1]:60s} {n/r/1e6:6.3f} M reads/s  (after chunk 1: {n2/max(r2,1
 PY
 }
 run "BMH_NOP=1" > /dev/null   # warm the runtime
-for e in "$@"; do run "$e"; done
+for e in "$@"; do sleep 3; run "$e"; done   # (a pause: the previous process is still tearing its GPU state down)
