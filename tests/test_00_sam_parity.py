@@ -174,6 +174,53 @@ def test_pe_250bp_mate_rescue_sam_identical(genome):
     assert ref_sam == _run(fa, [f1, f2], os.path.join(tmp, "dut_250l.sam"), extra, True, {"BMH_SW_WAVE": "0"})
 
 
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_fuzz_ragged_reads_sam_identical(genome, seed):
+    """Ragged input: lengths from below min_seed_len to 260, N runs, mates of different length, error rates from 0 to 15 %,
+    chimeric reads -- SE and PE, a different mix per seed."""
+    _, tmp, fa, ref = genome
+    rng = np.random.default_rng(seed)
+
+    def one(L, rate):
+        pos = int(rng.integers(0, len(ref) - 700))
+        ins = int(rng.integers(max(L, 60), 600))
+        frag = ref[pos:pos + ins + 40]
+        a = kswgen.mutate(rng, frag[:L + 30], rate, rate / 8, rate / 8, 3)[:L].copy()
+        if rng.random() < 0.15 and L > 60:  # chimera
+            cut = int(rng.integers(25, L - 25))
+            p2 = int(rng.integers(0, len(ref) - L))
+            a = np.concatenate([a[:cut], ref[p2:p2 + L - cut]]).copy()
+        if rng.random() < 0.2:
+            k = int(rng.integers(0, max(1, L - 5)))
+            a[k:k + int(rng.integers(1, 12))] = 4
+        return a, frag, ins
+
+    lens = [12, 18, 19, 20, 35, 50, 76, 100, 101, 125, 150, 151, 200, 250, 260]
+    se, p1, p2 = [], [], []
+    for _ in range(700):
+        a, _, _ = one(int(rng.choice(lens)), float(rng.choice([0.0, 0.01, 0.03, 0.08, 0.15])))
+        se.append(a if rng.random() < 0.5 else np.where(a[::-1] > 3, 4, 3 - a[::-1]).astype(np.uint8))
+    for _ in range(500):
+        L1, L2 = int(rng.choice(lens)), int(rng.choice(lens))
+        a, frag, ins = one(L1, float(rng.choice([0.0, 0.02, 0.06])))
+        lo = max(0, ins - L2)
+        b = kswgen.mutate(rng, frag[lo:lo + L2 + 30], float(rng.choice([0.01, 0.05, 0.12])), 0.004, 0.004, 2)[:L2]
+        if len(b) < 1:
+            continue
+        p1.append(a), p2.append(np.where(b[::-1] > 3, 4, 3 - b[::-1]).astype(np.uint8))
+    fq = os.path.join(tmp, f"fz{seed}.fq")
+    reflib.write_fastq(fq, se, "z")
+    extra = ["-t", "4", "-b", "173"]
+    assert _run(fa, [fq], os.path.join(tmp, f"ref_fz{seed}.sam"), extra, False) == \
+        _run(fa, [fq], os.path.join(tmp, f"dut_fz{seed}.sam"), extra, True, {"BMH_BATCH_EXACT": "1"})
+    f1, f2 = os.path.join(tmp, f"fz{seed}_1.fq"), os.path.join(tmp, f"fz{seed}_2.fq")
+    reflib.write_fastq(f1, p1, "y")
+    reflib.write_fastq(f2, p2, "y")
+    ref_sam = _run(fa, [f1, f2], os.path.join(tmp, f"ref_fzp{seed}.sam"), extra, False)
+    assert len(ref_sam) >= 2 * len(p1)
+    assert ref_sam == _run(fa, [f1, f2], os.path.join(tmp, f"dut_fzp{seed}.sam"), extra, True)
+
+
 def test_multi_contig_reference_sam_identical():
     """Three contigs of different length, reads that hang over contig ends and reads with N: exercises bwa_fix_xref2
     (reference bwa.c:179) in front of the CIGAR batch and the rid/pos conversion behind it, SE and PE."""
