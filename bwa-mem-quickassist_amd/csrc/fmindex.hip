@@ -287,12 +287,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
 	// the call is over: emit it (smem_next2's bookkeeping, bwamem.c:118-162) and decide what comes next
 	auto finish_call = [&](int n, int ret_) {
 		int mx = 0, mxk = 0, ne = 0; // ne = intervals long enough to be returned (bmh_smem_opt_t.min_emit_len)
-		uint64_t longm = 0;          // ... which ones, for calls of up to 64 intervals (more: the lengths are read again)
 		for (int k = 0; k < n; ++k) { // the longest match, first of equals (mem holds them back to front)
 			const uint64_t info = mem[n - 1 - k].info;
 			const int l = (int)((uint32_t)info - (uint32_t)(info >> 32));
 			if (!is_split && mx < l) mx = l, mxk = n - 1 - k;
-			if (l >= O.min_emit_len) ++ne, longm |= k < 64 ? 1ull << k : 0ull;
+			ne += l >= O.min_emit_len;
 		}
 		const unsigned long long ci = atomicAdd(&cursors[0], 1ull), base = atomicAdd(&cursors[1], (unsigned long long)ne);
 		if (ci < call_cap && base + ne <= intv_cap) {
@@ -300,9 +299,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES
 			c.x = x, c.min_intv = is_split ? mi2 : O.start_width, c.ret = ret_, c.n = ne, c.first = (uint32_t)base, c.rsv = (uint32_t)seq;
 			calls[ci] = c, call_read[ci] = (uint32_t)r;
 			for (int k = 0, w = 0; k < n && w < ne; ++k) {
-				if (k < 64 && !(longm >> k & 1)) continue;
 				const Intv v = mem[n - 1 - k];
-				if (k < 64 || (int)((uint32_t)v.info - (uint32_t)(v.info >> 32)) >= O.min_emit_len) intv[base + w++] = v;
+				if ((int)((uint32_t)v.info - (uint32_t)(v.info >> 32)) >= O.min_emit_len) intv[base + w++] = v;
 			}
 		} else atomicExch(overflow, 1);
 		++seq;
