@@ -174,6 +174,13 @@ int bmh_reg2cigar_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, const
 		const uint8_t *rq;
 		uint8_t *q, *t;
 		int i, tmp;
+		if (k + 8 < n_req) { /* the reads are scattered allocations of the host program's, the reference is hundreds of megabytes */
+			const bmh_cigar_req_t *nx = &reqs[k + 8];
+			const uint8_t *ns = reads[nx->read].seq + nx->qb;
+			const int64_t np = nx->rb >= l_pac ? (l_pac << 1) - nx->re : nx->rb;
+			__builtin_prefetch(ns), __builtin_prefetch(ns + 64), __builtin_prefetch(ns + 128);
+			if (np >= 0 && np < l_pac) __builtin_prefetch(pac + (np >> 2));
+		}
 		if (!c->valid) continue;
 		rq = reads[r->read].seq + r->qb, q = pool + c->q_off, t = pool + c->t_off;
 		if (!c->rev) {

@@ -828,6 +828,16 @@ int bmh_sam_batch(bmh_ctx_t *ctx, const bmh_sam_opt_t *o, const bmh_refidx_t *bn
 		const int nr = pe ? 2 : 1;
 		aln_t h[2], un;
 		int r, extra = 0;
+		if (i + 8 < n) { /* a read's name, bases and qualities are three allocations of the host program's: scattered */
+			const bmh_seq_t *nx = &seqs[i + 8];
+			__builtin_prefetch(nx->name), __builtin_prefetch(nx->seq), __builtin_prefetch(nx->seq + 64), __builtin_prefetch(nx->seq + 128);
+			if (nx->qual) __builtin_prefetch(nx->qual), __builtin_prefetch(nx->qual + 64), __builtin_prefetch(nx->qual + 128);
+			if (pe) {
+				++nx;
+				__builtin_prefetch(nx->name), __builtin_prefetch(nx->seq), __builtin_prefetch(nx->seq + 64), __builtin_prefetch(nx->seq + 128);
+				if (nx->qual) __builtin_prefetch(nx->qual), __builtin_prefetch(nx->qual + 64), __builtin_prefetch(nx->qual + 128);
+			}
+		}
 		unmapped(&un);
 		if (pe) {
 			const pairdec_t *d = &pd[i >> 1];
