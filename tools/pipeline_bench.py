@@ -2,7 +2,9 @@
 """Whole-pipeline DUT/REF timing on the GPU box (informational; bench.py is the contract metric).
 
 REF = the reference `bwa mem` compiled by oracle/Makefile; DUT = the same binary with
-libbwamem_hip_dropin.so preloaded (phase 1 through bmh_chain2aln_batch, ksw_global2 per-call on the GPU).
+libbwamem_hip_dropin.so preloaded (mem_process_seqs entirely on the library: seeding, chaining, extension, mate rescue,
+post-processing, SAM text).  Round 1's tool, kept for single-end runs and planted repeats; bench.py's pipeline_baseline and
+tools/pipeline_matrix.sh are what the numbers in DESIGN.md come from.
 Reads/s are taken from the reference's own per-chunk line
   [M::mem_process_seqs] Processed N reads in X CPU sec, Y real sec      (reference bwamem.c:1320-1321)
 which excludes index loading.  SAM equality is checked as well.
