@@ -191,7 +191,6 @@ int bmh_ctx_create(bmh_ctx_t **out, int device)
 	    (e = hipMalloc((void **)&ctx->d_err, sizeof(int))) != hipSuccess || (e = hipMemset(ctx->d_err, 0, sizeof(int))) != hipSuccess ||
 	    (e = hipHostMalloc((void **)&ctx->h_err, sizeof(int), hipHostMallocDefault)) != hipSuccess ||
 	    (e = hipEventCreate(&ctx->ev0)) != hipSuccess || (e = hipEventCreate(&ctx->ev1)) != hipSuccess ||
-	    (e = hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking)) != hipSuccess ||
 	    (e = hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming)) != hipSuccess ||
 	    (e = hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming)) != hipSuccess ||
 	    (e = hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming)) != hipSuccess ||

@@ -194,6 +194,8 @@ static int launch_extend_tiny(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext
 	return BMH_OK;
 }
 
+constexpr int64_t kForkMinTasks = 131072; // batches below this run their bins on one stream (see launch_extend)
+
 int launch_extend(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
                   bmh_ext_result_t *d_res, const uint32_t *d_order, int qmax, const uint32_t *d_n, int kind)
 {
@@ -238,8 +240,15 @@ int launch_extend(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_t
 	// Bins 0-2 (lane-per-task kernels, almost all tasks) run on the caller's stream; the few long flanks of bins 3-5
 	// (few waves, each running for many rows) run BESIDE them on a second stream instead of as a serial tail.
 	hipStream_t main_s = ctx->stream;
-	BMH_HIP(ctx, hipEventRecord(ctx->ev_fork, main_s));
-	BMH_HIP(ctx, hipStreamWaitEvent(ctx->aux_stream, ctx->ev_fork, 0));
+	// A small batch (the preload shim's: 33 k seeds) runs its bins one after the other on the caller's stream: the side
+	// stream buys nothing there, costs 2.7 ms to create per context and one more stream to share the hardware queues with.
+	const bool fork = n >= kForkMinTasks || ctx->ext_sched >= 0;
+	if (fork && !ctx->aux_stream) BMH_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+	hipStream_t side_s = fork ? ctx->aux_stream : main_s;
+	if (fork) {
+		BMH_HIP(ctx, hipEventRecord(ctx->ev_fork, main_s));
+		BMH_HIP(ctx, hipStreamWaitEvent(side_s, ctx->ev_fork, 0));
+	}
 	static const int orders[5][kExtBins] = {{3, 4, 5, 0, 1, 2}, {3, 4, 5, 2, 1, 0}, {3, 4, 5, 2, 1, 0}, {3, 4, 5, 2, 1, 0}, {2, 1, 0, 3, 4, 5}};
 	// 0: short bins first; 1: long bins first; 2: bins 0-1 behind the long flanks on the second stream, beside bin 2;
 	// 3: bins 0-1 on a third stream of their own (A/B knob BMH_EXT_SCHED)
@@ -247,7 +256,7 @@ int launch_extend(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_t
 	// short-query bins go behind them on the second stream and run beside the 128-column bin, whose two waves per SIMD leave
 	// issue slots free: 4.61 -> 4.41 ms per 1 M reads.  With many long flanks (100-300 bp reads) that delays bins 3-4, which
 	// are the critical path there (17.8 against 16.8 ms), so they keep the second stream to themselves.
-	const int sched = ctx->ext_sched >= 0 ? ctx->ext_sched : qmax <= 160 ? 2 : 1;
+	const int sched = ctx->ext_sched >= 0 ? ctx->ext_sched : !fork ? 1 : qmax <= 160 ? 2 : 1;
 	const int *order = orders[sched];
 	if (sched == 3) { // (an A/B knob: its stream is made when first asked for -- a stream costs 2.7 ms to create)
 		if (!ctx->aux2_stream) BMH_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux2_stream, hipStreamNonBlocking));
@@ -255,7 +264,7 @@ int launch_extend(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_t
 	}
 	for (int k = 0; k < kExtBins; ++k) {
 		const int b = order[k];
-		ctx->stream = b >= 3 ? ctx->aux_stream : b < 2 && (sched == 2 || sched == 4) ? ctx->aux_stream : b < 2 && sched == 3 ? ctx->aux2_stream : main_s; // the launchers enqueue on ctx->stream
+		ctx->stream = b >= 3 ? side_s : b < 2 && (sched == 2 || sched == 4) ? side_s : b < 2 && sched == 3 ? ctx->aux2_stream : main_s; // the launchers enqueue on ctx->stream
 		if (tm) {
 			rc = (int)hipEventRecord(ctx->ev_bin[b], ctx->stream);
 			if (rc) { ctx->stream = main_s; return set_hip_error(ctx, (hipError_t)rc, "hipEventRecord"); }
@@ -291,8 +300,10 @@ int launch_extend(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_t
 		if (rc) { ctx->stream = main_s; return rc; }
 	}
 	ctx->stream = main_s;
-	BMH_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->aux_stream));
-	BMH_HIP(ctx, hipStreamWaitEvent(main_s, ctx->ev_join, 0));
+	if (fork) {
+		BMH_HIP(ctx, hipEventRecord(ctx->ev_join, side_s));
+		BMH_HIP(ctx, hipStreamWaitEvent(main_s, ctx->ev_join, 0));
+	}
 	if (sched == 3) {
 		BMH_HIP(ctx, hipEventRecord(ctx->ev_join2, ctx->aux2_stream));
 		BMH_HIP(ctx, hipStreamWaitEvent(main_s, ctx->ev_join2, 0));
