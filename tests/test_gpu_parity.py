@@ -160,3 +160,26 @@ def test_staged_and_direct_transfers_agree(pkg):
     big = np.concatenate([pool, np.zeros(80 << 20, np.uint8)])             # > 64 MB up: not staged
     assert (c.extend_batch(big, tasks) == want).all()
     c.close()
+
+
+def test_sleeping_waits_give_the_same_results(pkg):
+    """bmh_set_wait_mode(1): host threads sleep on a blocking event instead of spinning on the stream -- what the preload
+    shim runs with.  Same calls, same results; the mode is process-wide and is put back."""
+    from test_kernel_families_gpu import _ctx_with
+    rng = np.random.default_rng(207)
+    p = kswlib.make_params()
+    pool, tasks = kswgen.gen_ext_realistic(rng, 3000)
+    want, _ = kswlib.orc_extend_batch(p, pool, tasks)
+    gpool, gt, words = kswgen.gen_glb_realistic(rng, 500)
+    gwant, _ = kswlib.orc_global_batch(p, gpool, gt)
+    lib = pkg.lib()
+    lib.bmh_set_wait_mode.restype = None
+    lib.bmh_set_wait_mode(1)
+    try:
+        c = _ctx_with({})  # created in sleeping mode: its device gets hipDeviceScheduleBlockingSync as well
+        assert (c.extend_batch(pool, tasks) == want).all()
+        res, _ = c.global_batch(gpool, gt, words)
+        assert (res == gwant).all()
+        c.close()
+    finally:
+        lib.bmh_set_wait_mode(0)
