@@ -242,6 +242,8 @@ void bmh_pestat(const bmh_sam_opt_t *o, int64_t l_pac, int n, const bmh_alnreg_v
 		const bmh_alnreg_v *r0 = &regs[i << 1 | 0], *r1 = &regs[i << 1 | 1];
 		int64_t is;
 		int dir;
+		if (i + 8 < n >> 1) /* every read's region vector is an allocation of its own: this serial loop is all cache misses */
+			__builtin_prefetch(regs[(i + 8) << 1].a), __builtin_prefetch(regs[(i + 8) << 1 | 1].a);
 		if (r0->n == 0 || r1->n == 0) continue;
 		if (cal_sub(o, r0) > MIN_RATIO * r0->a[0].score) continue;
 		if (cal_sub(o, r1) > MIN_RATIO * r1->a[0].score) continue;
@@ -629,6 +631,7 @@ int bmh_sam_batch(bmh_ctx_t *ctx, const bmh_sam_opt_t *o, const bmh_refidx_t *bn
 	/* ---- pass A: decisions */
 	if (!pe) {
 		for (i = 0; i < n; ++i) { /* worker2's SE branch, bwamem.c:1285-1289 */
+			if (i + 8 < n) __builtin_prefetch(regs[i + 8].a);
 			bmh_mark_primary_se(o, (int)regs[i].n, regs[i].a, id0 + i);
 			first[i] = W.n;
 			if ((rc = want_se(o, &W, i, &regs[i]))) goto done;
@@ -636,6 +639,7 @@ int bmh_sam_batch(bmh_ctx_t *ctx, const bmh_sam_opt_t *o, const bmh_refidx_t *bn
 	} else {
 		for (i = 0; i < n >> 1; ++i) { /* mem_sam_pe after its rescue block, bwamem_pair.c:264-331 */
 			bmh_alnreg_v *a = &regs[i << 1];
+			if (i + 6 < n >> 1) __builtin_prefetch(regs[(i + 6) << 1].a), __builtin_prefetch(regs[(i + 6) << 1 | 1].a);
 			const uint64_t id = (uint64_t)(id0 >> 1) + (uint64_t)i;
 			pairdec_t *d = &pd[i];
 			int sub_o = 0, n_sub = 0, oo, r, go_pair = 0;
