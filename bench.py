@@ -446,7 +446,7 @@ def main():
         for k in range(4):
             kernels.append({"kernel": "seedext " + names[k], "ms": float(round_ms[k]), "launches": n_chunks,
                             "algorithmic_bytes": ext_bytes / 2 if k in (0, 2) else 0.0})
-        gnames = ["global_lane_kernel<64> (ksw_global2 + traceback, w <= 31, 64 tasks/wave)", "global_lane_kernel<128> (w <= 63)",
+        gnames = ["global_lane_kernel<64> (ksw_global2 + traceback, w <= 31, 64 tasks/wave)", "global_lane_kernel<96> + <128> (32 <= w <= 47, 48 <= w <= 63)",
                   "global_kernel (one wave per task: wide bands, long targets)"]
         for b in range(3):
             kernels.append({"kernel": gnames[b], "ms": float(gbin_ms[b]), "launches": n_chunks, "tasks": int((gbin == b).sum()),

@@ -225,6 +225,7 @@ int bmh_ctx_create(bmh_ctx_t **out, int device)
 	if (const char *m = getenv("BMH_GLB_MODE")) ctx->glb_mode = !strcmp(m, "wave") ? 1 : 0;
 	if (const char *m = getenv("BMH_SW_MODE")) ctx->sw_mode = !strcmp(m, "generic") ? 1 : 0;
 	if (const char *m = getenv("BMH_SW_WAVE")) ctx->sw_wave = atoi(m) != 0;
+	if (const char *m = getenv("BMH_GL_FAST")) ctx->glb_fast = atoi(m) != 0;
 	if (const char *m = getenv("BMH_GRID_MULT")) ctx->grid_mult = atoi(m) > 0 ? atoi(m) : 1;
 	if (const char *m = getenv("BMH_EXT_SCHED")) ctx->ext_sched = atoi(m) >= 0 && atoi(m) <= 4 ? atoi(m) : -1;
 	*out = ctx;

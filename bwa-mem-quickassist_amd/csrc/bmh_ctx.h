@@ -31,6 +31,7 @@ struct bmh_ctx {
 	DevBuf d_zslab; // direction words of the lane-per-task global kernels, one slab per resident wave
 	int glb_mode = 0; // 0 lane-per-task global kernels, 1 one wave per task only (env BMH_GLB_MODE=wave)
 	int sw_mode = 0;  // 0 register kernels where they fit, 1 slab kernel only (env BMH_SW_MODE=generic)
+	int glb_fast = 1;   // unmasked body for blocks inside every lane's band (env BMH_GL_FAST=0 turns it off)
 	int sw_wave = 1;  // batches of up to 32 k tasks: one wave per task (sw_wave.hip); env BMH_SW_WAVE=0 turns it off
 	DevBuf d_bins; // per-launch bin lists of the extension dispatcher: 4 counters + 4 x n task indices
 	int grid_mult = 1;    // env BMH_GRID_MULT: persistent grid = resident waves x this (tuning knob)

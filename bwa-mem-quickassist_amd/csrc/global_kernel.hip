@@ -209,6 +209,7 @@ __global__ __launch_bounds__(64) void global_kernel(const uint8_t *__restrict__ 
 // ---- dispatcher -----------------------------------------------------------------------------------
 // bin 0: w <= 31  -> global_lane_kernel<64>   (64 tasks per wave, band-relative registers)
 // bin 1: w <= 63  -> global_lane_kernel<128>
+// bin 3: 32 <= w <= 47 -> global_lane_kernel<96>
 // bin 2: wider bands, targets longer than the lane kernels' direction slab, or scores that could leave the
 //        16-bit range -> global_kernel (one wave per task, int32 in LDS)
 // Bins and the order inside them (by row count) come from the same device-side counting sort as the extension path.
@@ -227,11 +228,11 @@ __global__ __launch_bounds__(256) void glb_sort_hist_kernel(const bmh_glb_task_t
 		const int qlen = tasks[idx].qlen, tlen = tasks[idx].tlen, w = tasks[idx].w;
 		const int worst = P.o_del + P.o_ins + emax * (qlen + tlen) + smax * max(qlen, tlen); // |score| bound of any cell
 		int bin = 2;
-		if (lane_ok && tlen <= rows_cap && worst < 12000 && w >= 0) bin = w <= 31 ? 0 : (w <= 63 ? 1 : 2);
+		if (lane_ok && tlen <= rows_cap && worst < 12000 && w >= 0) bin = w <= 31 ? 0 : w <= 47 ? 3 : (w <= 63 ? 1 : 2);
 		// inside a lane bin: rows first (lanes of a wave run until their longest target ends), then band width (a wave
 		// computes and stores the 8-slot blocks that ANY of its lanes needs, and its lanes' tracebacks share cache lines
 		// when they sit in the same block)
-		const int bk = bin * kSortKeysHost + (bin < 2 ? (min(tlen >> 3, 127) << 4 | (min(w, 63) >> (bin + 1) & 15)) : 0);
+		const int bk = bin * kSortKeysHost + (bin != 2 ? (min(tlen >> 3, 127) << 4 | (min(w, 63) >> (bin == 0 ? 1 : 2) & 15)) : 0);
 		binkey[k] = (uint16_t)bk;
 		atomicAdd(&lh[bk], 1u);
 	}
@@ -264,7 +265,10 @@ int launch_global(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_glb_task_t *d_t
 		if (tm) BMH_HIP(ctx, hipEventRecord(ctx->ev_gbin[0], ctx->stream));
 		if ((rc = launch_global_lane(ctx, 64, d_pool, d_tasks, n, d_res, d_cigar, lists, counts + 0, rows_cap))) return rc;
 		if (tm) BMH_HIP(ctx, hipEventRecord(ctx->ev_gbin[1], ctx->stream));
-		if (wgate > 31 && (rc = launch_global_lane(ctx, 128, d_pool, d_tasks, n, d_res, d_cigar, lists + N, counts + 1, rows_cap)))
+		// bands of 32..47 take the 96-slot instantiation (two waves per SIMD, three quarters of the slots), 48..63 the 128-slot one
+		if (wgate > 31 && (rc = launch_global_lane(ctx, 96, d_pool, d_tasks, n, d_res, d_cigar, lists + 3 * N, counts + 3, rows_cap)))
+			return rc;
+		if (wgate > 47 && (rc = launch_global_lane(ctx, 128, d_pool, d_tasks, n, d_res, d_cigar, lists + N, counts + 1, rows_cap)))
 			return rc;
 	}
 	if (tm) BMH_HIP(ctx, hipEventRecord(ctx->ev_gbin[2], ctx->stream));

@@ -24,6 +24,8 @@
 // (Round 1 stored a byte per cell for all C slots in [row][slot/4][lane] order: 3.35 GB of HBM traffic per 190 k tasks,
 // profiles/traffic_latest.json; most of it the traceback pulling a 64-byte sector per 4-byte read.)
 #include <algorithm>
+#include <cstdlib>
+#include <type_traits>
 
 #include "bmh_ctx.h"
 #include "bmh_device.h"
@@ -40,8 +42,12 @@ __device__ __forceinline__ int sel3(int mask, int a, int b) { return __builtin_a
 #ifndef BMH_GL_WAVES128
 #define BMH_GL_WAVES128 1
 #endif
-template <int C>
-__global__ __launch_bounds__(64, (C <= 64 ? BMH_GL_WAVES64 : BMH_GL_WAVES128)) void global_lane_kernel(
+#ifndef BMH_GL_WAVES96
+#define BMH_GL_WAVES96 2
+#endif
+
+template <int C, bool FAST>
+__global__ __launch_bounds__(64, (C <= 64 ? BMH_GL_WAVES64 : C <= 96 ? BMH_GL_WAVES96 : BMH_GL_WAVES128)) void global_lane_kernel(
     const uint8_t *__restrict__ pool, const bmh_glb_task_t *__restrict__ tasks, const uint32_t *__restrict__ order,
     const uint32_t *__restrict__ count, long long n, bmh_glb_result_t *__restrict__ out, uint32_t *__restrict__ cigar_pool,
     DevParams P, uint32_t *__restrict__ zslab, int rows_cap, int *__restrict__ err_flag)
@@ -131,28 +137,40 @@ __global__ __launch_bounds__(64, (C <= 64 ? BMH_GL_WAVES64 : BMH_GL_WAVES128)) v
 				// needed iff the block meets [slo-1, shi): slot slo-1 is the virtual column -1 that must receive `fill`
 				if (__builtin_amdgcn_ballot_w64(slo <= 8 * b + 8 && shi > 8 * b) == 0) continue;
 				uint32_t dz = 0;
+				// FAST: a block whose eight slots lie inside the band of EVERY lane still running needs no activity masks (no
+				// select on F, E and H, no fill); lanes past their last row compute garbage into their own registers
+				const bool masked = !FAST || __builtin_amdgcn_ballot_w64(rowon && !(slo <= 8 * b && shi >= 8 * b + 8)) != 0;
+				auto cells = [&](auto MASKED) {
 #pragma unroll
-				for (int c = 0; c < 8; ++c) {
-					const int s = 8 * b + c;
-					const int actv = (am[s / 32] << (31 - s % 32)) >> 31;
-					const unsigned sel = __builtin_amdgcn_perm((unsigned)QW[s / 4], row.y, 0x0c0c0c04u + (unsigned)(s % 4));
-					const int sc = (int)(int8_t)__builtin_amdgcn_perm(row.y, row.x, sel);
-					const int m = (int)(int16_t)(R[s] & 0xffff) + sc; // M(i,j) = H(i-1,j-1) + S, ksw.c:546
-					const int e = R[s + 1] >> 16;                      // E(i,j)
-					int d = m >= e ? 0 : 1;                            // ksw.c:547-550
-					int h = max(m, e);
-					d = h >= f ? d : 2;
-					h = max(h, f);
-					const int t1 = m - oe_del, e2 = e - e_del;         // ksw.c:552-556
-					d |= e2 > t1 ? 4 : 0;
-					const int en = max(e2, t1);
-					const int t2 = m - oe_ins, f2 = f - e_ins;         // ksw.c:557-560
-					d |= f2 > t2 ? 8 : 0;
-					f = sel3(actv, max(f2, t2), kNeg16);
-					// register s <- {H(i,j) for the next row's diagonal, E(i+1,j) for the next row's slot s-1}
-					R[s] = (int)__builtin_amdgcn_perm((unsigned)sel3(actv, en, kNeg16), (unsigned)sel3(actv, h, fill), 0x05040100u);
-					dz |= (uint32_t)d << (4 * c);
-				}
+					for (int c = 0; c < 8; ++c) {
+						const int s = 8 * b + c;
+						const unsigned sel = __builtin_amdgcn_perm((unsigned)QW[s / 4], row.y, 0x0c0c0c04u + (unsigned)(s % 4));
+						const int sc = (int)(int8_t)__builtin_amdgcn_perm(row.y, row.x, sel);
+						const int m = (int)(int16_t)(R[s] & 0xffff) + sc; // M(i,j) = H(i-1,j-1) + S, ksw.c:546
+						const int e = R[s + 1] >> 16;                      // E(i,j)
+						int d = m >= e ? 0 : 1;                            // ksw.c:547-550
+						int h = max(m, e);
+						d = h >= f ? d : 2;
+						h = max(h, f);
+						const int t1 = m - oe_del, e2 = e - e_del;         // ksw.c:552-556
+						d |= e2 > t1 ? 4 : 0;
+						const int en = max(e2, t1);
+						const int t2 = m - oe_ins, f2 = f - e_ins;         // ksw.c:557-560
+						d |= f2 > t2 ? 8 : 0;
+						// register s <- {H(i,j) for the next row's diagonal, E(i+1,j) for the next row's slot s-1}
+						if constexpr (decltype(MASKED)::value) {
+							const int actv = (am[s / 32] << (31 - s % 32)) >> 31;
+							f = sel3(actv, max(f2, t2), kNeg16);
+							R[s] = (int)__builtin_amdgcn_perm((unsigned)sel3(actv, en, kNeg16), (unsigned)sel3(actv, h, fill), 0x05040100u);
+						} else {
+							f = max(f2, t2);
+							R[s] = (int)__builtin_amdgcn_perm((unsigned)en, (unsigned)h, 0x05040100u);
+						}
+						dz |= (uint32_t)d << (4 * c);
+					}
+				};
+				if (masked) cells(std::true_type{});
+				else if constexpr (FAST) cells(std::false_type{});
 				if (want) zrow[(size_t)b * (size_t)rows_cap * 64] = dz; // ksw.c:561, eight cells at once
 			}
 			// score = eh[qlen].h after the LAST row of a lane = H(tlen-1, qlen-1), ksw.c:565: slot qlen-tlen+w of that row.
@@ -240,17 +258,25 @@ int launch_global_lane(bmh_ctx *ctx, int c, const uint8_t *d_pool, const bmh_glb
 	// persistent grid = the waves that are resident at once: every wave owns a private direction slab for as long as it
 	// lives, so more blocks than that would only pin more HBM (2 048 waves x 170 rows x 8 blocks x 256 B = 0.7 GB at
 	// 150 bp; a grow-only workspace per context, and the preload shim keeps one context per host thread)
-	const long long resident = (long long)ncu * 4 * (c <= 64 ? BMH_GL_WAVES64 : BMH_GL_WAVES128);
+	const long long resident = (long long)ncu * 4 * (c <= 64 ? BMH_GL_WAVES64 : c <= 96 ? BMH_GL_WAVES96 : BMH_GL_WAVES128);
 	if (grid > resident) grid = resident;
 	// one slab serves both lane kernels of a launch (they run back to back on the stream): [block][row][lane] dwords of
 	// 8 cells, C/8 blocks per row
 	const size_t slab = (size_t)grid * (size_t)rows_cap * (size_t)(c / 8) * 64 * 4;
 	int rc = ensure(ctx, ctx->d_zslab, slab);
 	if (rc) return rc;
-#define BMH_LAUNCH_GL(CC)                                                                                             \
-	hipLaunchKernelGGL(global_lane_kernel<CC>, dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_pool, d_tasks, d_order, \
-	                   d_count, (long long)n, d_res, d_cigar, ctx->dev, (uint32_t *)ctx->d_zslab.p, rows_cap, ctx->d_err)
+	const bool fast = ctx->glb_fast != 0; // (A/B knob BMH_GL_FAST: 0 = masked body only)
+#define BMH_LAUNCH_GL(CC)                                                                                                      \
+	do {                                                                                                                       \
+		if (fast)                                                                                                              \
+			hipLaunchKernelGGL((global_lane_kernel<CC, true>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_pool, d_tasks, d_order, \
+			                   d_count, (long long)n, d_res, d_cigar, ctx->dev, (uint32_t *)ctx->d_zslab.p, rows_cap, ctx->d_err);     \
+		else                                                                                                                   \
+			hipLaunchKernelGGL((global_lane_kernel<CC, false>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_pool, d_tasks, d_order, \
+			                   d_count, (long long)n, d_res, d_cigar, ctx->dev, (uint32_t *)ctx->d_zslab.p, rows_cap, ctx->d_err);    \
+	} while (0)
 	if (c == 64) BMH_LAUNCH_GL(64);
+	else if (c == 96) BMH_LAUNCH_GL(96);
 	else if (c == 128) BMH_LAUNCH_GL(128);
 	else return BMH_E_ARG;
 #undef BMH_LAUNCH_GL

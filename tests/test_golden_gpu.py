@@ -9,10 +9,11 @@ from __graft_entry__ import load_package
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def ctx():
-    pkg = load_package()
-    c = pkg.Context(0, kswlib.make_params())
+@pytest.fixture(scope="module", params=["default", "masked"])
+def ctx(request):
+    """"masked": the global lane kernels without the unmasked body for blocks inside every lane's band."""
+    from test_kernel_families_gpu import _ctx_with
+    c = _ctx_with({} if request.param == "default" else {"BMH_GL_FAST": "0"})
     yield c
     c.close()
 

@@ -18,10 +18,11 @@ def pkg():
 
 # Small batches (what these tests send) go to the one-task-per-wave kernels by default; "lane" keeps them on the
 # lane-per-task kernels that serve the large batches of the bench, so both production paths see every case below.
-@pytest.fixture(scope="module", params=["auto", "lane"])
+# The global lane kernels have one more switch: the unmasked body for blocks inside every lane's band ("masked" turns it off).
+@pytest.fixture(scope="module", params=["auto", "lane", "masked"])
 def ctx(pkg, request):
     from test_kernel_families_gpu import _ctx_with
-    c = _ctx_with({"BMH_EXT_SMALL": "0"} if request.param == "lane" else {})
+    c = _ctx_with({"auto": {}, "lane": {"BMH_EXT_SMALL": "0"}, "masked": {"BMH_EXT_SMALL": "0", "BMH_GL_FAST": "0"}}[request.param])
     yield c
     c.close()
 
