@@ -18,6 +18,8 @@ __global__ void sw_caps_kernel(const bmh_sw_task_t *__restrict__ tasks, long lon
 	if ((threadIdx.x & 63) == 0) atomicMax(&caps[0], q), atomicMax(&caps[1], t), atomicMax(&caps[2], qi);
 }
 
+// ---- batches of up to 32 768 tasks: sw_wave_kernel (one wave per task, sw_wave.hip) takes every task the register kernels
+//      would; the routing below then only feeds sw_generic_kernel (launch_sw)
 // ---- device-side routing: a counting sort by (kernel, query length, target length), like the extension dispatcher
 //   bin 0: byte mode, cannot overflow, padded query <= 80 columns   sw_lane_kernel<40>
 //   bin 1: ... <= 160 columns                                        sw_lane_kernel<80>
