@@ -325,6 +325,44 @@ class Context:
             out.append((calls[call_off[r]:call_off[r + 1]].copy(), intv[int(intv_off[r]):int(intv_off[r + 1])].copy()))
         return out
 
+    def seed_batch(self, opt, max_occ, reads):
+        """bmh_seed_batch: smem_batch plus, per interval, where its suffix-array positions start (sa_off, UINT64_MAX = not
+        looked up) and the positions.  Returns (per-read [(calls, intervals)], per-read sa_off arrays, sa_pos)."""
+        n = len(reads)
+        o_in, opt = np.asarray(opt), np.zeros((), dtype=SMEM_OPT)
+        for k in o_in.dtype.names:
+            opt[k] = o_in[k]
+        keep = []
+        c_reads = (_Read * max(n, 1))()
+        tot = 0
+        for k, r in enumerate(reads):
+            r = np.ascontiguousarray(r, dtype=np.uint8)
+            keep.append(r)
+            c_reads[k].l_seq, c_reads[k].seq = len(r), r.ctypes.data
+            tot += len(r)
+        call_cap, intv_cap, sa_cap = tot // 4 + 64 * n + 64, 2 * tot + 1024, 4 * tot + 4096
+        call_off = np.zeros(n + 1, dtype=np.uint32)
+        intv_off = np.zeros(n + 1, dtype=np.uint64)
+        n_pos = C.c_uint64(0)
+        while True:
+            calls = np.zeros(call_cap, dtype=SMEM_CALL)
+            intv = np.zeros(intv_cap, dtype=SMEM_INTV)
+            sa_off = np.zeros(intv_cap, dtype=np.uint64)
+            sa_pos = np.zeros(sa_cap, dtype=np.uint64)
+            rc = lib().bmh_seed_batch(self._h, _ptr(opt), C.c_int(int(max_occ)), n, C.cast(c_reads, C.c_void_p), _ptr(call_off), _ptr(calls),
+                                      C.c_size_t(call_cap), _ptr(intv_off), _ptr(intv), C.c_size_t(intv_cap), _ptr(sa_off), _ptr(sa_pos),
+                                      C.c_size_t(sa_cap), C.byref(n_pos))
+            if rc != BMH_E_CIGAR_CAP:
+                break
+            call_cap, intv_cap, sa_cap = 2 * call_cap, 4 * intv_cap, 4 * sa_cap
+        self._check(rc)
+        out, offs = [], []
+        for r in range(n):
+            lo, hi = int(intv_off[r]), int(intv_off[r + 1])
+            out.append((calls[call_off[r]:call_off[r + 1]].copy(), intv[lo:hi].copy()))
+            offs.append(sa_off[lo:hi].copy())
+        return out, offs, sa_pos[:n_pos.value].copy()
+
     def sa_batch(self, ks):
         """N x bwt_sa (reference bwt.c:85)."""
         ks = np.ascontiguousarray(ks, dtype=np.uint64)

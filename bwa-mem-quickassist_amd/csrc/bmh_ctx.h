@@ -24,7 +24,7 @@ struct bmh_ctx {
 	// device workspaces of the host-buffer entry points
 	DevBuf d_pool, d_tasks, d_res, d_order, d_cigar, d_scratch;
 	void *bwt_bind = nullptr; // FM-index binding (fmindex.hip), or null
-	double smem_calls_per_base = 0.06, smem_intv_per_base = 0.35; // high-water marks of bmh_smem_batch's output density
+	double smem_calls_per_base = 0.06, smem_intv_per_base = 0.35, smem_pos_per_base = 0.03; // high-water marks of bmh_smem_batch's / bmh_seed_batch's output density
 	const uint8_t *h_pac = nullptr; // host identity of the shared device copy of the 2-bit reference (bmh_ctx_set_pac)
 	DevBuf d_swrm;  // per-wave row maxima of the register Smith-Waterman kernels
 	DevBuf d_sw;    // row / row-maximum slabs of the local Smith-Waterman kernels

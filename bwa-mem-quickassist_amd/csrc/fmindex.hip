@@ -435,6 +435,49 @@ __global__ void sa_kernel(DevBwt B, const uint64_t *__restrict__ ks, long long n
 	}
 }
 
+// bwt_sa of one entry (the loop of sa_kernel)
+__device__ __forceinline__ uint64_t fm_sa(const DevBwt &B, uint64_t k)
+{
+	uint64_t sa = 0;
+	while (k & B.sa_mask) {
+		const uint64_t x = k - (k > B.primary);
+		const int c = (int)(B.bwt[((x >> 7) << 4) + 8 + ((x & 127) >> 4)] >> ((~x & 15) << 1) & 3);
+		++sa;
+		const U4 l2{B.L2[0], B.L2[1], B.L2[2], B.L2[3]}, l2n{B.L2[1], B.L2[2], B.L2[3], B.L2[4]};
+		if (k == B.primary) k = 0;
+		else if (k == B.seq_len) k = pick(l2n, c);
+		else k = pick(l2, c) + pick(fm_occ4(B, k), c);
+	}
+	return sa + B.sa[k >> B.sa_shift];
+}
+
+// The suffix-array entries mem_insert_seed will ask for (bwamem.c:218-225), looked up where the intervals are: one thread
+// per interval the SMEM kernel wrote; an interval long and rare enough (length >= min_seed_len, x[2] <= max_occ) takes
+// x[2] slots of `pos` (cursor[2]) and notes where they start in pos_base[slot], the others note UINT64_MAX.  The interval
+// count is read from the SMEM kernel's cursor: no host round trip between the two kernels.
+__global__ void sa_of_intervals_kernel(DevBwt B, const Intv *__restrict__ intv, const unsigned long long *__restrict__ cursors,
+                                       unsigned long long intv_cap, int min_seed_len, unsigned long long max_occ,
+                                       uint64_t *__restrict__ pos_base, uint64_t *__restrict__ pos, unsigned long long pos_cap,
+                                       unsigned long long *__restrict__ pos_cursor, int *__restrict__ overflow)
+{
+	const unsigned long long n = min(cursors[1], intv_cap);
+	for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (unsigned long long)gridDim.x * blockDim.x) {
+		const Intv v = intv[t];
+		const int len = (int)((uint32_t)v.info - (uint32_t)(v.info >> 32));
+		if (len < min_seed_len || v.x2 > max_occ) {
+			pos_base[t] = ~0ull;
+			continue;
+		}
+		const unsigned long long base = atomicAdd(pos_cursor, (unsigned long long)v.x2);
+		pos_base[t] = base;
+		if (base + v.x2 > pos_cap) {
+			atomicExch(overflow, 1);
+			continue;
+		}
+		for (uint64_t j = 0; j < v.x2; ++j) pos[base + j] = fm_sa(B, v.x0 + j);
+	}
+}
+
 // ---- host side: one resident copy of the index per (device, host arrays), shared by all contexts ----
 struct BwtShare {
 	int device;
@@ -534,8 +577,16 @@ int bmh_sa_batch(bmh_ctx_t *ctx, const uint64_t *k, int64_t n, uint64_t *pos)
 	return BMH_OK;
 }
 
-int bmh_smem_batch(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const bmh_read_t *reads, uint32_t *call_off,
-                   bmh_smem_call_t *calls, size_t call_cap, uint64_t *intv_off, bmh_smem_intv_t *intv, size_t intv_cap)
+// what bmh_seed_batch adds to bmh_smem_batch: the suffix-array positions of the intervals chaining will look up
+struct SeedPos {
+	int min_seed_len, max_occ;
+	uint64_t *sa_off, *sa_pos; // sa_off[k] for interval k of the output, UINT64_MAX = never looked up
+	size_t sa_cap;
+	uint64_t n_pos;            // out: positions written
+};
+
+static int smem_impl(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const bmh_read_t *reads, uint32_t *call_off,
+                     bmh_smem_call_t *calls, size_t call_cap, uint64_t *intv_off, bmh_smem_intv_t *intv, size_t intv_cap, SeedPos *sp)
 {
 	if (!ctx || !o || n_reads < 0 || (n_reads > 0 && (!reads || !call_off || !intv_off))) return BMH_E_ARG;
 	if (!ctx->bwt_bind) {
@@ -590,17 +641,20 @@ int bmh_smem_batch(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const b
 	// batches does not run the kernel twice
 	size_t d_calls = std::max<size_t>((size_t)(ctx->smem_calls_per_base * 1.25 * (double)bytes) + 1024, 1024);
 	size_t d_intv = std::max<size_t>((size_t)(ctx->smem_intv_per_base * 1.25 * (double)bytes) + 4096, 4096);
+	size_t d_pos = sp ? std::max<size_t>((size_t)(ctx->smem_pos_per_base * 1.25 * (double)bytes) + 4096, 4096) : 0;
 	const bmh_smem_call_t *h_calls = nullptr; // (in the pinned download buffer)
 	const uint32_t *h_read = nullptr;
 	const Intv *h_intv = nullptr;
+	const uint64_t *h_pb = nullptr, *h_pos = nullptr; // bmh_seed_batch: where an interval's positions start; the positions
 	size_t n_calls = 0;
-	unsigned long long totals[2] = {0, 0};
+	unsigned long long totals[5] = {0, 0, 0, 0, 0}; // calls, intervals, (overflow flag), (read counter), positions
 	if ((rc = ensure_host(ctx, ctx->h_down, 64))) return rc;
 	tt[1] = now();
 	for (int attempt = 0; attempt < 6; ++attempt) {
 		const size_t hdr = 64, o_pool = hdr, o_off = o_pool + ((bytes + 16 + 63) & ~(size_t)63), o_len = o_off + (size_t)n_reads * 8,
 		             o_calls = (o_len + (size_t)n_reads * 4 + 63) & ~(size_t)63, o_cr = o_calls + d_calls * sizeof(bmh_smem_call_t),
-		             o_intv = (o_cr + d_calls * 4 + 63) & ~(size_t)63, total = o_intv + d_intv * sizeof(Intv);
+		             o_intv = (o_cr + d_calls * 4 + 63) & ~(size_t)63, o_pb = o_intv + d_intv * sizeof(Intv), o_pos = o_pb + (sp ? d_intv * 8 : 0),
+		             total = o_pos + d_pos * 8;
 		if ((rc = ensure(ctx, ctx->d_scratch, total))) return rc;
 		if ((rc = ensure(ctx, ctx->d_sw, (size_t)grid * 3 * (size_t)lcap * 64 * sizeof(Intv)))) return rc;
 		uint8_t *d = (uint8_t *)ctx->d_scratch.p;
@@ -625,22 +679,34 @@ int bmh_smem_batch(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const b
 #undef BMH_SMEM_LAUNCH_CONV
 #undef BMH_SMEM_LAUNCH
 		BMH_HIP(ctx, hipGetLastError());
+		if (sp) { // the positions of the intervals just written, straight behind them on the stream
+			hipLaunchKernelGGL(sa_of_intervals_kernel, dim3((unsigned)std::min<size_t>((d_intv + 255) / 256, 4096)), dim3(256), 0, ctx->stream, B,
+			                   (const Intv *)(d + o_intv), (const unsigned long long *)d, (unsigned long long)d_intv, sp->min_seed_len,
+			                   (unsigned long long)sp->max_occ, (uint64_t *)(d + o_pb), (uint64_t *)(d + o_pos), (unsigned long long)d_pos,
+			                   (unsigned long long *)(d + 32), (int *)(d + 16));
+			BMH_HIP(ctx, hipGetLastError());
+		}
 		if (ctx->timing) {
 			BMH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
 			ctx->ev_valid = true;
 		}
-		BMH_HIP(ctx, hipMemcpyAsync(ctx->h_down.p, d, 16, hipMemcpyDeviceToHost, ctx->stream));
+		BMH_HIP(ctx, hipMemcpyAsync(ctx->h_down.p, d, 40, hipMemcpyDeviceToHost, ctx->stream));
 		BMH_HIP(ctx, stream_wait(ctx, ctx->stream));
-		memcpy(totals, ctx->h_down.p, 16);
+		memcpy(totals, ctx->h_down.p, 40);
+		if (sp) ctx->smem_pos_per_base = std::max(ctx->smem_pos_per_base, (double)totals[4] / (double)std::max<size_t>(bytes, 1));
 		ctx->smem_calls_per_base = std::max(ctx->smem_calls_per_base, (double)totals[0] / (double)std::max<size_t>(bytes, 1));
 		ctx->smem_intv_per_base = std::max(ctx->smem_intv_per_base, (double)totals[1] / (double)std::max<size_t>(bytes, 1));
 		tt[2] = now();
-		if (totals[0] <= d_calls && totals[1] <= d_intv) {
+		if (totals[0] <= d_calls && totals[1] <= d_intv && (!sp || totals[4] <= d_pos)) {
 			n_calls = (size_t)totals[0];
 			const size_t b_calls = n_calls * sizeof(bmh_smem_call_t), b_read = (n_calls * 4 + 63) & ~(size_t)63, b_intv = (size_t)totals[1] * sizeof(Intv);
-			if ((rc = ensure_host(ctx, ctx->h_down, b_calls + b_read + b_intv + 64))) return rc;
+			const size_t b_pb = sp ? (size_t)totals[1] * 8 : 0, b_pos = sp ? (size_t)totals[4] * 8 : 0;
+			if ((rc = ensure_host(ctx, ctx->h_down, b_calls + b_read + b_intv + b_pb + b_pos + 64))) return rc;
 			uint8_t *h = (uint8_t *)ctx->h_down.p;
 			h_calls = (const bmh_smem_call_t *)h, h_read = (const uint32_t *)(h + b_calls), h_intv = (const Intv *)(h + b_calls + b_read);
+			h_pb = (const uint64_t *)(h + b_calls + b_read + b_intv), h_pos = (const uint64_t *)(h + b_calls + b_read + b_intv + b_pb);
+			if (b_pb) BMH_HIP(ctx, hipMemcpyAsync(h + b_calls + b_read + b_intv, d + o_pb, b_pb, hipMemcpyDeviceToHost, ctx->stream));
+			if (b_pos) BMH_HIP(ctx, hipMemcpyAsync(h + b_calls + b_read + b_intv + b_pb, d + o_pos, b_pos, hipMemcpyDeviceToHost, ctx->stream));
 			if (n_calls) {
 				BMH_HIP(ctx, hipMemcpyAsync(h, d + o_calls, b_calls, hipMemcpyDeviceToHost, ctx->stream));
 				BMH_HIP(ctx, hipMemcpyAsync(h + b_calls, d + o_cr, n_calls * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -650,9 +716,10 @@ int bmh_smem_batch(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const b
 			break;
 		}
 		d_calls = std::max(d_calls, (size_t)totals[0] + 64), d_intv = std::max(d_intv, (size_t)totals[1] + 64);
+		if (sp) d_pos = std::max(d_pos, (size_t)totals[4] + 64);
 		if (attempt == 5) return BMH_E_NOMEM;
 	}
-	if (totals[0] > call_cap || totals[1] > intv_cap || (totals[0] && (!calls || (!intv && totals[1])))) {
+	if (totals[0] > call_cap || totals[1] > intv_cap || (totals[0] && (!calls || (!intv && totals[1]))) || (sp && totals[4] > sp->sa_cap)) {
 		ctx->last_error = "bmh_smem_batch: " + std::to_string(totals[0]) + " calls / " + std::to_string(totals[1]) +
 		                  " intervals do not fit the caller's arrays";
 		return BMH_E_CIGAR_CAP;
@@ -671,16 +738,38 @@ int bmh_smem_batch(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const b
 		for (uint32_t c = call_off[r]; c < call_off[r + 1]; ++c) {
 			bmh_smem_call_t &cl = calls[c];
 			if (cl.n) memcpy(&intv[used + local], &h_intv[cl.first], (size_t)cl.n * sizeof(Intv));
+			if (cl.n && sp) memcpy(&sp->sa_off[used + local], &h_pb[cl.first], (size_t)cl.n * 8);
 			cl.first = (uint32_t)local, cl.rsv = 0, local += (uint64_t)cl.n;
 		}
 		used += local;
 	}
 	intv_off[n_reads] = used;
+	if (sp) {
+		if (totals[4]) memcpy(sp->sa_pos, h_pos, (size_t)totals[4] * 8);
+		sp->n_pos = totals[4];
+	}
 	tt[4] = now();
 	if (trace)
 		fprintf(stderr, "[bwamem_hip] bmh_smem_batch %d reads: prepare %.1f ms, upload+kernel %.1f ms, download %.1f ms, reorder %.1f ms\n", n_reads,
 		        (tt[1] - tt[0]) * 1e3, (tt[2] - tt[1]) * 1e3, (tt[3] - tt[2]) * 1e3, (tt[4] - tt[3]) * 1e3);
 	return BMH_OK;
+}
+
+int bmh_smem_batch(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const bmh_read_t *reads, uint32_t *call_off,
+                   bmh_smem_call_t *calls, size_t call_cap, uint64_t *intv_off, bmh_smem_intv_t *intv, size_t intv_cap)
+{
+	return smem_impl(ctx, o, n_reads, reads, call_off, calls, call_cap, intv_off, intv, intv_cap, nullptr);
+}
+
+int bmh_seed_batch(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int max_occ, int n_reads, const bmh_read_t *reads, uint32_t *call_off,
+                   bmh_smem_call_t *calls, size_t call_cap, uint64_t *intv_off, bmh_smem_intv_t *intv, size_t intv_cap, uint64_t *sa_off,
+                   uint64_t *sa_pos, size_t sa_cap, uint64_t *n_pos)
+{
+	if (!o || max_occ < 0 || (n_reads > 0 && (!sa_off || (!sa_pos && sa_cap)))) return BMH_E_ARG;
+	SeedPos sp{o->min_seed_len, max_occ, sa_off, sa_pos, sa_cap, 0};
+	const int rc = smem_impl(ctx, o, n_reads, reads, call_off, calls, call_cap, intv_off, intv, intv_cap, &sp);
+	if (n_pos) *n_pos = sp.n_pos;
+	return rc;
 }
 
 } // extern "C"

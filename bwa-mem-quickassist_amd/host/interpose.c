@@ -208,7 +208,7 @@ typedef struct {
 	uint64_t *sa_k, *sa_pos; /* per interval: where its run of positions starts (bmh_chain_sa_keys); the positions */
 	size_t n_sa;
 } qa_seed_t;
-static double g_seed_density[2] = {0.06, 0.02};
+static double g_seed_density[3] = {0.06, 0.02, 0.03}; /* calls, intervals, suffix-array positions per base */
 static long long g_seed_us[3]; /* thread-microseconds: bmh_smem_batch, building the look-up keys, bmh_sa_batch */
 static __thread qa_seed_t *qa_seed; /* the batch this thread is chaining */
 
@@ -233,38 +233,64 @@ static void qa_seed_batch_begin(bmh_ctx_t *ctx, const ref_mem_opt_t *opt, const 
 	S = (qa_seed_t *)calloc(1, sizeof(*S));
 	S->bwt = bwt, S->n_reads = n, S->reads = reads;
 	S->call_off = (uint32_t *)malloc(4 * ((size_t)n + 1)), S->intv_off = (uint64_t *)malloc(8 * ((size_t)n + 1));
-	/* output arrays sized from the densest batch seen so far in this process (calls / intervals per base) */
+	/* output arrays sized from the densest batch seen so far in this process (calls / intervals / positions per base) */
 	ts[0] = stage_now();
-	for (call_cap = (size_t)(g_seed_density[0] * 1.3 * (double)tot) + 4 * (size_t)n + 64,
-	    intv_cap = (size_t)(g_seed_density[1] * 1.3 * (double)tot) + 1024;;
-	     call_cap *= 2, intv_cap *= 2) {
-		S->calls = (bmh_smem_call_t *)malloc(sizeof(bmh_smem_call_t) * call_cap);
-		S->intv = (bmh_smem_intv_t *)malloc(sizeof(bmh_smem_intv_t) * intv_cap);
-		rc = bmh_smem_batch(ctx, &so, n, reads, S->call_off, S->calls, call_cap, S->intv_off, S->intv, intv_cap);
-		if (rc != BMH_E_CIGAR_CAP) break;
-		free(S->calls), free(S->intv);
+	if (!(getenv("BMH_SEED_FUSED") && getenv("BMH_SEED_FUSED")[0] == '0')) {
+		/* SMEMs and the suffix-array entries chaining will ask for (bwamem.c:218-225) in one device round trip */
+		size_t sa_cap;
+		uint64_t n_pos = 0;
+		for (call_cap = (size_t)(g_seed_density[0] * 1.3 * (double)tot) + 4 * (size_t)n + 64,
+		    intv_cap = (size_t)(g_seed_density[1] * 1.3 * (double)tot) + 1024, sa_cap = (size_t)(g_seed_density[2] * 1.3 * (double)tot) + 4096;;
+		     call_cap *= 2, intv_cap *= 2, sa_cap *= 2) {
+			S->calls = (bmh_smem_call_t *)malloc(sizeof(bmh_smem_call_t) * call_cap);
+			S->intv = (bmh_smem_intv_t *)malloc(sizeof(bmh_smem_intv_t) * intv_cap);
+			S->sa_k = (uint64_t *)malloc(8 * intv_cap), S->sa_pos = (uint64_t *)malloc(8 * sa_cap);
+			rc = bmh_seed_batch(ctx, &so, opt->max_occ, n, reads, S->call_off, S->calls, call_cap, S->intv_off, S->intv, intv_cap, S->sa_k, S->sa_pos,
+			                    sa_cap, &n_pos);
+			if (rc != BMH_E_CIGAR_CAP) break;
+			free(S->calls), free(S->intv), free(S->sa_k), free(S->sa_pos);
+		}
+		if (rc) bmh_tls_die(bmh_last_error(ctx), rc);
+		S->n_sa = (size_t)n_pos;
+		ts[1] = ts[2] = ts[3] = stage_now();
+		if (tot) { /* (a benign race: statistics that only size buffers) */
+			const double dc = (double)S->call_off[n] / (double)tot, di = (double)S->intv_off[n] / (double)tot, dp = (double)n_pos / (double)tot;
+			if (dc > g_seed_density[0]) g_seed_density[0] = dc;
+			if (di > g_seed_density[1]) g_seed_density[1] = di;
+			if (dp > g_seed_density[2]) g_seed_density[2] = dp;
+		}
+	} else { /* the same in three calls (the A/B path): bmh_smem_batch, bmh_chain_sa_keys, bmh_sa_batch */
+		for (call_cap = (size_t)(g_seed_density[0] * 1.3 * (double)tot) + 4 * (size_t)n + 64,
+		    intv_cap = (size_t)(g_seed_density[1] * 1.3 * (double)tot) + 1024;;
+		     call_cap *= 2, intv_cap *= 2) {
+			S->calls = (bmh_smem_call_t *)malloc(sizeof(bmh_smem_call_t) * call_cap);
+			S->intv = (bmh_smem_intv_t *)malloc(sizeof(bmh_smem_intv_t) * intv_cap);
+			rc = bmh_smem_batch(ctx, &so, n, reads, S->call_off, S->calls, call_cap, S->intv_off, S->intv, intv_cap);
+			if (rc != BMH_E_CIGAR_CAP) break;
+			free(S->calls), free(S->intv);
+		}
+		if (rc) bmh_tls_die(bmh_last_error(ctx), rc);
+		ts[1] = stage_now();
+		if (tot) {
+			const double dc = (double)S->call_off[n] / (double)tot, di = (double)S->intv_off[n] / (double)tot;
+			if (dc > g_seed_density[0]) g_seed_density[0] = dc;
+			if (di > g_seed_density[1]) g_seed_density[1] = di;
+		}
+		{
+			bmh_chain_opt_t co;
+			memset(&co, 0, sizeof(co));
+			co.min_seed_len = opt->min_seed_len, co.max_occ = opt->max_occ;
+			S->sa_k = (uint64_t *)malloc(8 * (S->intv_off[n] + 1)); /* here: sa_off, one entry per interval */
+			nk = (size_t)bmh_chain_sa_keys(&co, S->intv_off[n], S->intv, S->sa_k, 0);
+			keys = (uint64_t *)malloc(8 * (nk + 1)), S->sa_pos = (uint64_t *)malloc(8 * (nk + 1));
+			bmh_chain_sa_keys(&co, S->intv_off[n], S->intv, S->sa_k, keys);
+			S->n_sa = nk;
+		}
+		ts[2] = stage_now();
+		if ((rc = bmh_sa_batch(ctx, keys, (int64_t)nk, S->sa_pos))) bmh_tls_die(bmh_last_error(ctx), rc);
+		free(keys);
+		ts[3] = stage_now();
 	}
-	if (rc) bmh_tls_die(bmh_last_error(ctx), rc);
-	ts[1] = stage_now();
-	if (tot) { /* (a benign race: statistics that only size buffers) */
-		const double dc = (double)S->call_off[n] / (double)tot, di = (double)S->intv_off[n] / (double)tot;
-		if (dc > g_seed_density[0]) g_seed_density[0] = dc;
-		if (di > g_seed_density[1]) g_seed_density[1] = di;
-	}
-	{ /* the suffix-array entries chaining will ask for, in interval order (bmh_chain_sa_keys), resolved by one GPU batch */
-		bmh_chain_opt_t co;
-		memset(&co, 0, sizeof(co));
-		co.min_seed_len = opt->min_seed_len, co.max_occ = opt->max_occ;
-		S->sa_k = (uint64_t *)malloc(8 * (S->intv_off[n] + 1)); /* here: sa_off, one entry per interval */
-		nk = (size_t)bmh_chain_sa_keys(&co, S->intv_off[n], S->intv, S->sa_k, 0);
-		keys = (uint64_t *)malloc(8 * (nk + 1)), S->sa_pos = (uint64_t *)malloc(8 * (nk + 1));
-		bmh_chain_sa_keys(&co, S->intv_off[n], S->intv, S->sa_k, keys);
-		S->n_sa = nk;
-	}
-	ts[2] = stage_now();
-	if ((rc = bmh_sa_batch(ctx, keys, (int64_t)nk, S->sa_pos))) bmh_tls_die(bmh_last_error(ctx), rc);
-	free(keys);
-	ts[3] = stage_now();
 	__sync_fetch_and_add(&g_seed_us[0], (long long)((ts[1] - ts[0]) * 1e6)), __sync_fetch_and_add(&g_seed_us[1], (long long)((ts[2] - ts[1]) * 1e6));
 	__sync_fetch_and_add(&g_seed_us[2], (long long)((ts[3] - ts[2]) * 1e6));
 	qa_seed = S;

@@ -522,6 +522,15 @@ int bmh_ctx_set_bwt(bmh_ctx_t *ctx, const bmh_bwt_t *bwt);
  * intv_off have n_reads+1 entries.  BMH_E_CIGAR_CAP if a capacity is too small (nothing partial is returned). */
 int bmh_smem_batch(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const bmh_read_t *reads, uint32_t *call_off,
                    bmh_smem_call_t *calls, size_t call_cap, uint64_t *intv_off, bmh_smem_intv_t *intv, size_t intv_cap);
+/* bmh_smem_batch + the suffix-array look-ups chaining will make, in ONE device round trip: for every interval that comes
+ * back and is long and rare enough to become seeds (length >= o->min_seed_len, x[2] <= max_occ; bwamem.c:218-225),
+ * sa_off[k] = index of its first position in sa_pos (its x[2] positions follow one another: bwt_sa(x[0] + j)), for the
+ * others UINT64_MAX -- what bmh_chain_sa_keys + bmh_sa_batch produce, in the form bmh_chain_reads takes (the runs lie in
+ * sa_pos in no particular order).  sa_off has intv_cap entries.  *n_pos (nullable) = positions written.
+ * BMH_E_CIGAR_CAP if a capacity is too small. */
+int bmh_seed_batch(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int max_occ, int n_reads, const bmh_read_t *reads, uint32_t *call_off,
+                   bmh_smem_call_t *calls, size_t call_cap, uint64_t *intv_off, bmh_smem_intv_t *intv, size_t intv_cap, uint64_t *sa_off,
+                   uint64_t *sa_pos, size_t sa_cap, uint64_t *n_pos);
 /* N x bwt_sa: pos[i] = position (doubled coordinate) of suffix-array entry k[i]. */
 int bmh_sa_batch(bmh_ctx_t *ctx, const uint64_t *k, int64_t n, uint64_t *pos);
 

@@ -87,3 +87,48 @@ def test_smem_min_emit_len_returns_the_long_intervals_only(kernel, monkeypatch):
         n_all += len(full[r][1])
     assert 0 < n_kept < n_all / 4
     ctx.close()
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_seed_batch_is_smem_batch_plus_the_suffix_array_lookups(kernel, monkeypatch):
+    """bmh_seed_batch: the intervals of bmh_smem_batch and, for each one chaining would look up (length >= min_seed_len,
+    x[2] <= max_occ), its suffix-array positions -- the same numbers as bmh_sa_batch / the oracle's bwt_sa, in one call."""
+    monkeypatch.setenv("BMH_SMEM_KERNEL", kernel)
+    cb, keep, raw, opt, reads, per, sa_k, sa_pos = kswlib.golden_fmindex()
+    rng = np.random.default_rng(197)
+    src = np.concatenate(reads)
+    more = list(reads)
+    for _ in range(1500):
+        L = int(rng.choice([19, 20, 75, 150, 151, 300]))
+        p = int(rng.integers(0, len(src) - L))
+        rd = src[p:p + L].copy()
+        m = rng.random(L) < rng.choice([0.0, 0.02, 0.12])
+        rd[m] = (rd[m] + rng.integers(1, 4, m.sum())) % 5
+        more.append(rd)
+    ctx = _ctx_with({})
+    ctx.set_bwt(*raw)
+    for emit, max_occ in ((0, 10000), (int(opt["min_seed_len"]), 10000), (int(opt["min_seed_len"]), 3)):
+        o2 = np.array(opt, dtype=kswlib.SMEM_OPT).copy()
+        o2["min_emit_len"] = emit
+        got, offs, pos = ctx.seed_batch(o2, max_occ, more)
+        plain = ctx.smem_batch(o2, more)
+        n_looked = n_skipped = 0
+        want_keys, got_pos = [], []
+        for r, ((gc, gi), (pc, pi), so) in enumerate(zip(got, plain, offs)):
+            assert _same_calls((gc, gi), (pc, pi)), f"read {r}"
+            ln = (gi["info"] & np.uint64(0xffffffff)).astype(np.int64) - (gi["info"] >> np.uint64(32)).astype(np.int64)
+            look = (ln >= int(opt["min_seed_len"])) & (gi["x2"] <= max_occ)
+            assert ((so != np.uint64(0xffffffffffffffff)) == look).all(), f"read {r}"
+            n_looked += int(look.sum())
+            n_skipped += int((~look).sum())
+            for k in np.nonzero(look)[0]:
+                x0, x2, b = int(gi["x0"][k]), int(gi["x2"][k]), int(so[k])
+                want_keys.append(np.arange(x0, x0 + x2, dtype=np.uint64))
+                got_pos.append(pos[b:b + x2])
+        assert n_looked > 1000 and (emit or n_skipped > 1000)
+        keys = np.concatenate(want_keys)
+        assert len(keys) == len(pos)  # every position slot belongs to exactly one interval
+        assert (np.concatenate(got_pos) == ctx.sa_batch(keys)).all()
+        sample = rng.choice(len(keys), 300, replace=False)
+        assert (np.concatenate(got_pos)[sample] == kswlib.orc_sa(cb, keys[sample])).all()
+    ctx.close()
