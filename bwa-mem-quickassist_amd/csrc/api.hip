@@ -847,6 +847,22 @@ int bmh_ctx_reserve_device(bmh_ctx_t *ctx, size_t pool_bytes, int64_t max_tasks,
 	return BMH_OK;
 }
 
+int bmh_ctx_reserve_kernels(bmh_ctx_t *ctx, int seed_reads, int seed_read_len, int64_t global_tasks, int global_rows)
+{
+	if (!ctx || seed_reads < 0 || seed_read_len < 0 || global_tasks < 0 || global_rows < 0) return BMH_E_ARG;
+	int rc;
+	BMH_HIP(ctx, hipSetDevice(ctx->device));
+	if (seed_reads > 0) { // the SMEM kernels' interval stacks (fmindex.hip): three per lane, read length + 2 entries of 32 bytes each
+		const size_t grid = std::min<size_t>(((size_t)seed_reads + 63) / 64, 1024 * 4);
+		if ((rc = ensure(ctx, ctx->d_sw, grid * 3 * ((size_t)seed_read_len + 2) * 64 * 32))) return rc;
+	}
+	if (global_tasks > 0) { // the lane kernels' direction slab (global_lane.hip): resident waves x rows x 8 blocks x 256 bytes
+		const size_t grid = std::min<size_t>(((size_t)global_tasks + 63) / 64, (size_t)std::max(ctx->ncu, 1) * 4 * 2);
+		if ((rc = ensure(ctx, ctx->d_zslab, grid * (size_t)std::min(global_rows, 512) * 8 * 256))) return rc;
+	}
+	return BMH_OK;
+}
+
 int bmh_driver_stats(const bmh_ctx_t *ctx, bmh_driver_stats_t *st)
 {
 	if (!ctx || !st) return BMH_E_ARG;

@@ -49,6 +49,11 @@ static void pool_reserve(bmh_ctx_t *ctx)
 	if (mb == 0) return;
 	(void)bmh_ctx_reserve_staging(ctx, mb << 20, mb << 20);
 	(void)bmh_ctx_reserve_device(ctx, mb << 20, (int64_t)(mb << 10) * 2, (mb << 20) / 8);
+	{ /* the kernels' own workspaces for batches of the shim's size: 40 k reads of up to 160 bases per seeding batch, 70 k
+	   * global alignments of up to 192 rows per slice of phase 2 ($BMH_RESERVE_KERNELS=0: grow on demand) */
+		const char *k = getenv("BMH_RESERVE_KERNELS");
+		if (!(k && k[0] == '0')) (void)bmh_ctx_reserve_kernels(ctx, (int)(mb * 2500), 160, (int64_t)mb * 4400, 192);
+	}
 }
 
 void bmh_tls_die(const char *msg, int code)

@@ -336,6 +336,11 @@ int bmh_ctx_reserve_staging(bmh_ctx_t *ctx, size_t upload_bytes, size_t download
  * words, the dispatcher's sort lists): growing one of them in the middle of a run frees and re-allocates device memory,
  * which synchronises the device under every other host thread's batch. */
 int bmh_ctx_reserve_device(bmh_ctx_t *ctx, size_t pool_bytes, int64_t max_tasks, size_t cigar_words);
+/* ... and the two large kernel workspaces, which otherwise grow inside a context's first batches (a hipMalloc of hundreds
+ * of megabytes under every other thread's work): the SMEM kernels' interval stacks for batches of up to seed_reads reads of
+ * up to seed_read_len bases, and the ksw_global2 lane kernels' direction slab for batches of up to global_tasks tasks with
+ * targets of up to global_rows rows.  0 skips either. */
+int bmh_ctx_reserve_kernels(bmh_ctx_t *ctx, int seed_reads, int seed_read_len, int64_t global_tasks, int global_rows);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Local Smith-Waterman for mate rescue and short chains.
