@@ -155,9 +155,9 @@ int launch_sw_lane(bmh_ctx *ctx, int b, bool corr, bool word, const uint8_t *d_p
                    int grid, int pass2, uint32_t *d_next);
 bool sw_wave_fits(int64_t n, int qcap, int tcap);
 int launch_sw_wave(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks, int64_t n, bmh_sw_result_t *d_res, int max_cols,
-                   int tcap);
+                   int tcap, const uint32_t *d_order = nullptr, const uint32_t *d_count = nullptr);
 int launch_sw_generic(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks, int64_t n,
-                      bmh_sw_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, int qcap, int tcap);
+                      bmh_sw_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, int qcap, int tcap, int wave_cols = 0);
 int launch_extend_lane(bmh_ctx *ctx, int c, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
                        bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, bool exact);
 int launch_extend_reg(bmh_ctx *ctx, int ns, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,

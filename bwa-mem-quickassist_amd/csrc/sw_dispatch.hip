@@ -149,7 +149,14 @@ int launch_sw(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks,
 		if ((rc = launch_sw_lane(ctx, 80, true, false, d_pool, d_tasks, n, d_res, lists + 4 * N, counts + 4, d_rm, tcap, grid, pass2, counts + 12))) return rc;
 		if ((rc = launch_sw_lane(ctx, 40, false, false, d_pool, d_tasks, n, d_res, lists, counts, d_rm, tcap, grid, pass2, counts + 8))) return rc;
 		if ((rc = launch_sw_lane(ctx, 40, true, false, d_pool, d_tasks, n, d_res, lists + 3 * N, counts + 3, d_rm, tcap, grid, pass2, counts + 11))) return rc;
-		if (!pass2 && (rc = launch_sw_generic(ctx, d_pool, d_tasks, n, d_res, lists + 2 * N, counts + 2, qcap, tcap))) return rc;
+		if (!pass2) {
+			// what the register kernels do not take (more than 256 columns: reads of 260-300 bp) but one wave per task does
+			// (up to 320 columns, arithmetic that cannot saturate) goes to sw_wave_kernel over the bin's list; the slab kernel
+			// serves the rest (it used to serve all of it: 37 ms per launch for a handful of 300 bp mates, however few)
+			const int wc = ctx->sw_mode == 0 && ctx->sw_wave && tcap <= 16384 && qcap - 16 > 256 ? 320 : 0;
+			if (wc && (rc = launch_sw_wave(ctx, d_pool, d_tasks, n, d_res, wc, tcap, lists + 2 * N, counts + 2))) return rc;
+			if ((rc = launch_sw_generic(ctx, d_pool, d_tasks, n, d_res, lists + 2 * N, counts + 2, qcap, tcap, wc))) return rc;
+		}
 	}
 	if (ctx->timing) {
 		BMH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));

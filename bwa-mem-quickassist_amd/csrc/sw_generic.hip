@@ -109,7 +109,7 @@ __global__ __launch_bounds__(64) void sw_generic_kernel(const uint8_t *__restric
                                                         const uint32_t *__restrict__ order,
                                                         const uint32_t *__restrict__ count, long long n,
                                                         bmh_sw_result_t *__restrict__ out, DevParams P, uint8_t *slab,
-                                                        long long slab_stride, int qcap, int tcap, int *err_flag)
+                                                        long long slab_stride, int qcap, int tcap, int *err_flag, int wave_cols)
 {
 	__shared__ int smat[6 * 8];
 	const int lane = threadIdx.x;
@@ -133,6 +133,7 @@ __global__ __launch_bounds__(64) void sw_generic_kernel(const uint8_t *__restric
 		const bool byte_mode = xtra & BMH_SW_XBYTE;
 		const int p = byte_mode ? 16 : 8;
 		const int Q = (qlen + p - 1) / p * p;
+		if (wave_cols > 0 && sw_wave_takes(P, qlen, xtra, wave_cols)) continue; // sw_wave_kernel has been through this list
 		bmh_sw_result_t res;
 		res.score = 0, res.te = res.qe = res.score2 = res.te2 = res.tb = res.qb = -1, res.rsv = 0;
 		if (Q > qcap || tlen > tcap || sw_task_out_of_range(P, qlen, xtra)) {
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(64) void sw_generic_kernel(const uint8_t *__restric
 }
 
 int launch_sw_generic(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks, int64_t n,
-                      bmh_sw_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, int qcap, int tcap)
+                      bmh_sw_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, int qcap, int tcap, int wave_cols)
 {
 	if (n <= 0) return BMH_OK;
 	qcap = (qcap + 15) / 16 * 16;
@@ -178,7 +179,7 @@ int launch_sw_generic(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_sw_task_t *
 	if ((rc = ensure(ctx, ctx->d_sw, stride * (size_t)grid))) return rc;
 	hipLaunchKernelGGL(sw_generic_kernel, dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_pool, d_tasks, d_order,
 	                   d_count, (long long)n, d_res, ctx->dev, (uint8_t *)ctx->d_sw.p, (long long)stride, qcap, tcap,
-	                   ctx->d_err);
+	                   ctx->d_err, wave_cols);
 	BMH_HIP(ctx, hipGetLastError());
 	return BMH_OK;
 }

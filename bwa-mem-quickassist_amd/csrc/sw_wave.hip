@@ -137,7 +137,8 @@ __device__ SwCore sw_pass_wave(const SwWaveSeq &seq, const DevParams &P, const u
 template <int CPL>
 __global__ __launch_bounds__(64) void sw_wave_kernel(const uint8_t *__restrict__ pool, const bmh_sw_task_t *__restrict__ tasks,
                                                      long long n, bmh_sw_result_t *__restrict__ out, DevParams P,
-                                                     int rows_cap, int *__restrict__ err_flag)
+                                                     int rows_cap, int *__restrict__ err_flag,
+                                                     const uint32_t *__restrict__ order, const uint32_t *__restrict__ count)
 {
 	__shared__ uint2 srow[8];            // [t] = scores of target base t against {A, C, G, T, N, pad, -, -}, biased by 128
 	extern __shared__ uint16_t rmax[];   // [rows_cap] row maxima of the task, for the second-best score (ksw.c:181-189)
@@ -152,7 +153,9 @@ __global__ __launch_bounds__(64) void sw_wave_kernel(const uint8_t *__restrict__
 		srow[lane] = make_uint2(lo, hi);
 	}
 	__syncthreads();
-	for (long long k = blockIdx.x; k < n; k += gridDim.x) {
+	const long long cnt = count ? (long long)*count : n; // a bin of the dispatcher's sort (order, count) or the whole batch
+	for (long long kk = blockIdx.x; kk < cnt; kk += gridDim.x) {
+		const long long k = order ? (long long)order[kk] : kk;
 		const bmh_sw_task_t tk = tasks[k];
 		const int qlen = tk.qlen, tlen = (int)min(tk.tlen, 0x7fffffffu);
 		const uint32_t xtra = tk.xtra;
@@ -191,15 +194,18 @@ bool sw_wave_fits(int64_t n, int qcap, int tcap)
 }
 
 int launch_sw_wave(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks, int64_t n, bmh_sw_result_t *d_res, int max_cols,
-                   int tcap)
+                   int tcap, const uint32_t *d_order, const uint32_t *d_count)
 {
-	const unsigned grid = (unsigned)std::min<int64_t>(n, 65536);
+	// a list whose length lives on the device (a bin of the sort) gets a grid for a few thousand tasks and strides over the rest
+	const unsigned grid = (unsigned)std::min<int64_t>(n, d_count ? 16384 : 65536);
 	const int rows_cap = (std::max(tcap, 1) + 63) & ~63;
 	const size_t lds = (size_t)rows_cap * sizeof(uint16_t);
 	if (max_cols <= 64 * 3)
-		hipLaunchKernelGGL(sw_wave_kernel<3>, dim3(grid), dim3(64), lds, ctx->stream, d_pool, d_tasks, (long long)n, d_res, ctx->dev, rows_cap, ctx->d_err);
+		hipLaunchKernelGGL(sw_wave_kernel<3>, dim3(grid), dim3(64), lds, ctx->stream, d_pool, d_tasks, (long long)n, d_res, ctx->dev, rows_cap, ctx->d_err,
+		                   d_order, d_count);
 	else
-		hipLaunchKernelGGL(sw_wave_kernel<5>, dim3(grid), dim3(64), lds, ctx->stream, d_pool, d_tasks, (long long)n, d_res, ctx->dev, rows_cap, ctx->d_err);
+		hipLaunchKernelGGL(sw_wave_kernel<5>, dim3(grid), dim3(64), lds, ctx->stream, d_pool, d_tasks, (long long)n, d_res, ctx->dev, rows_cap, ctx->d_err,
+		                   d_order, d_count);
 	BMH_HIP(ctx, hipGetLastError());
 	return BMH_OK;
 }

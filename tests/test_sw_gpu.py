@@ -179,3 +179,17 @@ def test_sw_edge_sizes():
     ctx = _ctx_with({})
     _cmp(ctx.sw_batch(pool, tasks), want, tasks, "edge sizes")
     ctx.close()
+
+
+def test_sw_wide_queries_in_a_large_batch():
+    """More than 32 768 tasks (so the lane-per-task kernels serve the batch) with queries of up to 300 columns: what exceeds the
+    register kernels' 256 columns goes to the one-wave-per-task kernel over the dispatcher's list, not to the slab kernel."""
+    ctx = _sw_ctx("wave")
+    rng = np.random.default_rng(1301)
+    p = kswlib.make_params()
+    ctx.set_params(p)
+    pool, tasks = kswgen.gen_sw_materescue(rng, 36000, p, read_len=(120, 300), win=(150, 700), hard=True)
+    assert int((tasks["qlen"] > 256).sum()) > 2000 and int((tasks["qlen"] <= 160).sum()) > 2000
+    want, _ = kswlib.orc_sw_batch(p, pool, tasks, nthreads=8)
+    _cmp(ctx.sw_batch(pool, tasks), want, tasks, "large batch with wide queries")
+    ctx.close()
