@@ -65,3 +65,25 @@ def test_bench_round1_line_still_runs():
     _contract(d, 3, 1)
     assert d["config"]["workload"].startswith("se1m")
     assert d["global_alignment"]["parity"].startswith("bit-exact") and d["mate_rescue_sw"]["parity"].startswith("bit-exact")
+
+
+def test_bench_two_ranks_on_one_device_and_the_host_fed_step():
+    """`bench.py --gpus 2` must start by itself (no RANK in the environment): two rank processes, here both mapped onto the one visible
+    device (--oversubscribe: gloo for the barrier and the report), static shard per rank, one line with n_gpus 2 and one time per rank;
+    and the host-fed steps (uploads one chunk ahead on a copy stream, results downloaded, inside the timed region) report `value_streamed`
+    with the same results as the resident steps (the line's parity covers host-fed == resident)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--oversubscribe", "--steps", "2", "--warmup", "1", "--pairs", "60000",
+                        "--chunk-reads", "40000", "--no-cpu-baseline", "--no-pipeline-baseline"], capture_output=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and len(d["per_rank_ms_per_step"]) == 2 and all(t > 0 for t in d["per_rank_ms_per_step"])
+    assert d["parity"].startswith("bit-exact") and d["value"] > 0
+    # weak scaling: value counts both ranks' reads over the slower rank's time
+    assert abs(d["value"] - 2 * d["config"]["reads_per_gpu"] / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    st = d["streamed"]
+    assert d["value_streamed"] == st["value_streamed"] > 0 and st["h2d_bytes_per_step"] > 0 and st["d2h_bytes_per_step"] > 0
+    assert st["h2d_GBps_copy_stream"] and st["h2d_GBps_copy_stream"] > 0.1
+    assert d["value_streamed"] <= d["value"] * 1.25  # the fed step cannot be meaningfully faster than the resident one

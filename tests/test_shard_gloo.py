@@ -65,3 +65,21 @@ def test_contiguous_split_tiles_the_batch():
             assert r[0][0] == 0 and r[-1][1] == n
             assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
             assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` without RANK/WORLD_SIZE must start N rank processes itself (before any GPU call) and relay rank 0's
+    line -- round 2's harness asserted here.  --rank-echo makes every rank report its environment and exit without touching a GPU."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--rank-echo"], capture_output=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stderr.decode()[-1000:]
+    d = json.loads(r.stdout.decode().strip())
+    assert d["RANK"] == "0" and d["LOCAL_RANK"] == "0" and d["WORLD_SIZE"] == "3" and d["MASTER_ADDR"] == "127.0.0.1" and int(d["MASTER_PORT"]) > 0
+    # and a wrong WORLD_SIZE is a message, not an assertion
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-pipeline-baseline"], capture_output=True, timeout=120,
+                       env=dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"))
+    assert r.returncode != 0 and b"launches its own ranks" in r.stderr

@@ -49,6 +49,7 @@ def main(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--global-tasks", type=int, default=250_000,
                     help="size of the secondary ksw_global2 measurement (0 = skip); rank 0 at N=1 only")
+    ap.add_argument("--oversubscribe", action="store_true")
     args = ap.parse_args(argv)
 
     import torch
@@ -62,11 +63,18 @@ def main(argv=None):
     # under torch.distributed.run (RANK set) the process group is always created -- also for one rank -- so the
     # RCCL path is the same code at N=1,2,4,8; a bare `python bench.py` stays single-process
     use_dist = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if world != args.gpus:
+        sys.exit(f"bench_se1m: --gpus {args.gpus} but WORLD_SIZE={world}: start it as `python bench.py --workload se1m --gpus N` "
+                 f"(bench.py launches its own ranks) or under torch.distributed.run")
+    if args.oversubscribe:  # rehearsal: more ranks than devices, report over gloo (bench.py --oversubscribe)
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        if args.oversubscribe:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -133,7 +141,7 @@ def main(argv=None):
     ctx.sync()  # surfaces any BMH_E_RANGE flagged by the kernel
     if use_dist:
         dist.barrier()
-    elapsed, reads_all, tasks_all = sh.reduce_report(elapsed, n_reads_used, n_tasks, dev)
+    elapsed, reads_all, tasks_all = sh.reduce_report(elapsed, n_reads_used, n_tasks, torch.device("cpu") if args.oversubscribe else dev)
 
     # ---- secondary measurement: the banded global alignment + traceback kernel (row a2), N=1 only
     glb = None
