@@ -492,6 +492,34 @@ def extend_batch_sharded(ctxs, pool, tasks):
     return res
 
 
+def _sharded(fn, ctxs, pool, tasks, tdtype, rdtype, *more):
+    pool = np.ascontiguousarray(pool, dtype=np.uint8)
+    tasks = np.ascontiguousarray(tasks, dtype=tdtype)
+    res = np.zeros(len(tasks), dtype=rdtype)
+    arr = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    rc = getattr(lib(), fn)(arr, len(ctxs), _ptr(pool), C.c_size_t(pool.nbytes), _ptr(tasks), C.c_int64(len(tasks)), _ptr(res), *more)
+    if rc:
+        raise BmhError(rc, lib().bmh_strerror(rc).decode())
+    return res
+
+
+def seedext_batch_sharded(ctxs, pool, tasks):
+    """Fused per-seed records, one contiguous slice per context (bmh_seedext_batch_sharded)."""
+    return _sharded("bmh_seedext_batch_sharded", ctxs, pool, tasks, SEED_TASK, SEED_RES)
+
+
+def sw_batch_sharded(ctxs, pool, tasks):
+    """ksw_align2 tasks, one contiguous slice per context (bmh_sw_batch_sharded)."""
+    return _sharded("bmh_sw_batch_sharded", ctxs, pool, tasks, SW_TASK, SW_RES)
+
+
+def global_batch_sharded(ctxs, pool, tasks, cigar_words):
+    """ksw_global2 + traceback, one contiguous slice per context (bmh_global_batch_sharded) -> (results, CIGAR pool)."""
+    cig = np.zeros(max(int(cigar_words), 1), dtype=np.uint32)
+    res = _sharded("bmh_global_batch_sharded", ctxs, pool, tasks, GLB_TASK, GLB_RES, _ptr(cig), C.c_size_t(int(cigar_words)))
+    return res, cig
+
+
 def declared_symbols():
     """Every function name declared in include/bwamem_hip.h (for the symbol-export test)."""
     import re

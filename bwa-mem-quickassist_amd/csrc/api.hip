@@ -696,6 +696,29 @@ int bmh_seedext_stats(const bmh_ctx_t *ctx, bmh_seedext_stats_t *st)
 
 // ------------------------------------------------------------------ global
 
+struct GlbShape {
+	int qmax = 1, tmax = 1, wmax = 0, wraw = 0;
+	size_t cig_lo = ~(size_t)0, cig_hi = 0; // the words of the CIGAR pool the tasks may write
+};
+static int validate_glb(bmh_ctx *ctx, const bmh_glb_task_t *tasks, int64_t n, size_t pool_bytes, bool have_cigar_pool, size_t cigar_words, GlbShape *o)
+{
+	GlbShape g;
+	for (int64_t k = 0; k < n; ++k) {
+		const bmh_glb_task_t &x = tasks[k];
+		if (x.q_off + x.qlen > pool_bytes || x.t_off + x.tlen > pool_bytes || x.w < 0 ||
+		    (x.cigar_cap && (!have_cigar_pool || (size_t)x.cigar_off + x.cigar_cap > cigar_words))) {
+			ctx->last_error = "global task " + std::to_string(k) + " has out-of-range offsets";
+			return BMH_E_ARG;
+		}
+		g.qmax = std::max(g.qmax, (int)x.qlen), g.tmax = std::max(g.tmax, (int)x.tlen);
+		g.wmax = std::max(g.wmax, std::min(x.w, (int)x.qlen)); // only min(qlen,2w+1) columns are ever stored
+		g.wraw = std::max(g.wraw, x.w);                        // ... but the device bins the tasks by their w as given
+		if (x.cigar_cap) g.cig_lo = std::min(g.cig_lo, (size_t)x.cigar_off), g.cig_hi = std::max(g.cig_hi, (size_t)x.cigar_off + x.cigar_cap);
+	}
+	*o = g;
+	return BMH_OK;
+}
+
 int bmh_global_batch_device(bmh_ctx_t *ctx, const uint8_t *d_pool, const bmh_glb_task_t *d_tasks, int64_t n,
                             bmh_glb_result_t *d_res, uint32_t *d_cigar, const uint32_t *d_order)
 {
@@ -720,18 +743,10 @@ int bmh_global_batch(bmh_ctx_t *ctx, const uint8_t *pool, size_t pool_bytes, con
 		if (!ctx->pool_resident) return BMH_E_ARG;
 		pool_bytes = ctx->pool_bytes;
 	}
-	int qmax = 1, tmax = 1, wmax = 0, wraw = 0, rc;
-	for (int64_t k = 0; k < n; ++k) {
-		const bmh_glb_task_t &x = tasks[k];
-		if (x.q_off + x.qlen > pool_bytes || x.t_off + x.tlen > pool_bytes || x.w < 0 ||
-		    (x.cigar_cap && (!cigar_pool || (size_t)x.cigar_off + x.cigar_cap > cigar_words))) {
-			ctx->last_error = "global task " + std::to_string(k) + " has out-of-range offsets";
-			return BMH_E_ARG;
-		}
-		qmax = std::max(qmax, (int)x.qlen), tmax = std::max(tmax, (int)x.tlen);
-		wmax = std::max(wmax, std::min(x.w, (int)x.qlen)); // only min(qlen,2w+1) columns are ever stored
-		wraw = std::max(wraw, x.w);                        // ... but the device bins the tasks by their w as given
-	}
+	GlbShape gs;
+	int rc;
+	if ((rc = validate_glb(ctx, tasks, n, pool_bytes, cigar_pool != nullptr, cigar_words, &gs))) return rc;
+	const int qmax = gs.qmax, tmax = gs.tmax, wmax = gs.wmax, wraw = gs.wraw;
 	GateGuard gate;
 	BMH_HIP(ctx, hipSetDevice(ctx->device));
 	if (!resident) {
@@ -769,19 +784,9 @@ int bmh_sw_batch_device(bmh_ctx_t *ctx, const uint8_t *d_pool, const bmh_sw_task
 	return launch_sw(ctx, d_pool, d_tasks, n, d_res, -1, -1, -1);
 }
 
-int bmh_sw_batch(bmh_ctx_t *ctx, const uint8_t *pool, size_t pool_bytes, const bmh_sw_task_t *tasks, int64_t n,
-                 bmh_sw_result_t *results)
+static int validate_sw(bmh_ctx *ctx, const bmh_sw_task_t *tasks, int64_t n, size_t pool_bytes, int *qmax_, int *tmax_, int *qmin_)
 {
-	if (!ctx || n < 0 || (n > 0 && (!tasks || !results))) return BMH_E_ARG;
-	if (!ctx->have_params) return BMH_E_ARG;
-	if (n == 0) return BMH_OK;
-	if (n > 0xffffffffLL) return BMH_E_ARG;
-	const bool resident = pool == nullptr; // use the pool left on the device by bmh_upload_pool()
-	if (resident) {
-		if (!ctx->pool_resident) return BMH_E_ARG;
-		pool_bytes = ctx->pool_bytes;
-	}
-	int qmax = 1, tmax = 1, qmin = 65535, rc;
+	int qmax = 1, tmax = 1, qmin = 65535;
 	for (int64_t k = 0; k < n; ++k) {
 		const bmh_sw_task_t &x = tasks[k];
 		qmin = std::min(qmin, (int)x.qlen);
@@ -804,6 +809,24 @@ int bmh_sw_batch(bmh_ctx_t *ctx, const uint8_t *pool, size_t pool_bytes, const b
 		}
 		qmax = std::max(qmax, (int)x.qlen), tmax = std::max(tmax, (int)x.tlen);
 	}
+	*qmax_ = qmax, *tmax_ = tmax, *qmin_ = qmin;
+	return BMH_OK;
+}
+
+int bmh_sw_batch(bmh_ctx_t *ctx, const uint8_t *pool, size_t pool_bytes, const bmh_sw_task_t *tasks, int64_t n,
+                 bmh_sw_result_t *results)
+{
+	if (!ctx || n < 0 || (n > 0 && (!tasks || !results))) return BMH_E_ARG;
+	if (!ctx->have_params) return BMH_E_ARG;
+	if (n == 0) return BMH_OK;
+	if (n > 0xffffffffLL) return BMH_E_ARG;
+	const bool resident = pool == nullptr; // use the pool left on the device by bmh_upload_pool()
+	if (resident) {
+		if (!ctx->pool_resident) return BMH_E_ARG;
+		pool_bytes = ctx->pool_bytes;
+	}
+	int qmax = 1, tmax = 1, qmin = 65535, rc;
+	if ((rc = validate_sw(ctx, tasks, n, pool_bytes, &qmax, &tmax, &qmin))) return rc;
 	GateGuard gate;
 	BMH_HIP(ctx, hipSetDevice(ctx->device));
 	if (!resident) {
@@ -824,6 +847,137 @@ int bmh_sw_batch(bmh_ctx_t *ctx, const uint8_t *pool, size_t pool_bytes, const b
 	st.finish();
 	return rc;
 }
+
+// ------------------------------------------------------------------ static shards of the other batches
+// One contiguous slice of the tasks per context (one context per GPU), every device given the whole sequence pool (offsets stay
+// valid), everything -- uploads, kernels, downloads -- enqueued on every device's stream before any of them is waited for; no
+// collective, no device-to-device traffic.  The same split as kt_for_batch's ranges (reference kthread_batch.c:44-56, bwamem.c:1313).
+} // extern "C"
+static void drain_shards(bmh_ctx_t *const *ctxs, int upto)
+{
+	for (int h = 0; h <= upto; ++h) {
+		(void)hipSetDevice(ctxs[h]->device);
+		(void)stream_wait(ctxs[h], ctxs[h]->stream);
+	}
+}
+template <class Enqueue> static int run_sharded(bmh_ctx_t *const *ctxs, int n_ctx, int64_t n, Enqueue enqueue)
+{
+	if (!ctxs || n_ctx < 1 || n < 0) return BMH_E_ARG;
+	for (int g = 0; g < n_ctx; ++g)
+		if (!ctxs[g] || !ctxs[g]->have_params) return BMH_E_ARG;
+	if (n == 0) return BMH_OK;
+	for (int g = 0; g < n_ctx; ++g) {
+		const int64_t lo = n * g / n_ctx, m = n * (g + 1) / n_ctx - lo;
+		if (m == 0) continue;
+		bmh_ctx *c = ctxs[g];
+		int rc = hipSetDevice(c->device) == hipSuccess ? BMH_OK : BMH_E_HIP;
+		if (!rc) rc = enqueue(c, g, lo, m);
+		if (rc) { // copies into the caller's arrays may be in flight on the devices already served: drain them first
+			drain_shards(ctxs, g);
+			return rc;
+		}
+	}
+	int first = BMH_OK;
+	for (int g = 0; g < n_ctx; ++g) {
+		if (n * (g + 1) / n_ctx == n * g / n_ctx) continue;
+		BMH_HIP(ctxs[g], hipSetDevice(ctxs[g]->device));
+		const int rc = fetch_err(ctxs[g]); // synchronises
+		if (rc && !first) first = rc;
+	}
+	return first;
+}
+#define SH_TRY(expr)                                                                                                   \
+	do {                                                                                                               \
+		if ((expr) != hipSuccess) {                                                                                    \
+			c->last_error = std::string(#expr) + ": " + hipGetErrorString(hipGetLastError());                          \
+			return BMH_E_HIP;                                                                                          \
+		}                                                                                                              \
+	} while (0)
+
+extern "C" {
+int bmh_seedext_batch_sharded(bmh_ctx_t *const *ctxs, int n_ctx, const uint8_t *pool, size_t pool_bytes, const bmh_seed_task_t *tasks,
+                              int64_t n, bmh_seed_result_t *results)
+{
+	if (n > 0 && (!pool || !tasks || !results)) return BMH_E_ARG;
+	return run_sharded(ctxs, n_ctx, n, [&](bmh_ctx *c, int, int64_t lo, int64_t m) -> int {
+		int qmax = 1, rc;
+		if (m > 0x7fffffffLL) return BMH_E_ARG;
+		if ((rc = validate_seeds(c, tasks + lo, m, pool_bytes, &qmax))) return rc;
+		c->pool_resident = false;
+		if ((rc = ensure(c, c->d_pool, pool_bytes + 16)) || (rc = ensure(c, c->d_tasks, (size_t)m * sizeof(bmh_seed_task_t) + 64)) ||
+		    (rc = ensure(c, c->d_res, (size_t)m * sizeof(bmh_seed_result_t) + 64)))
+			return rc;
+		SH_TRY(hipMemcpyAsync(c->d_pool.p, pool, pool_bytes, hipMemcpyHostToDevice, c->stream));
+		SH_TRY(hipMemcpyAsync(c->d_tasks.p, tasks + lo, (size_t)m * sizeof(bmh_seed_task_t), hipMemcpyHostToDevice, c->stream));
+		if ((rc = launch_seedext(c, (const uint8_t *)c->d_pool.p, (const bmh_seed_task_t *)c->d_tasks.p, m, (bmh_seed_result_t *)c->d_res.p, qmax)))
+			return rc;
+		SH_TRY(hipMemcpyAsync(results + lo, c->d_res.p, (size_t)m * sizeof(bmh_seed_result_t), hipMemcpyDeviceToHost, c->stream));
+		return BMH_OK;
+	});
+}
+
+int bmh_sw_batch_sharded(bmh_ctx_t *const *ctxs, int n_ctx, const uint8_t *pool, size_t pool_bytes, const bmh_sw_task_t *tasks, int64_t n,
+                         bmh_sw_result_t *results)
+{
+	if (n > 0 && (!pool || !tasks || !results)) return BMH_E_ARG;
+	return run_sharded(ctxs, n_ctx, n, [&](bmh_ctx *c, int, int64_t lo, int64_t m) -> int {
+		int qmax = 1, tmax = 1, qmin = 65535, rc;
+		if ((rc = validate_sw(c, tasks + lo, m, pool_bytes, &qmax, &tmax, &qmin))) return rc;
+		c->pool_resident = false;
+		if ((rc = ensure(c, c->d_pool, pool_bytes + 16)) || (rc = ensure(c, c->d_tasks, (size_t)m * sizeof(bmh_sw_task_t))) ||
+		    (rc = ensure(c, c->d_res, (size_t)m * sizeof(bmh_sw_result_t))))
+			return rc;
+		SH_TRY(hipMemcpyAsync(c->d_pool.p, pool, pool_bytes, hipMemcpyHostToDevice, c->stream));
+		SH_TRY(hipMemcpyAsync(c->d_tasks.p, tasks + lo, (size_t)m * sizeof(bmh_sw_task_t), hipMemcpyHostToDevice, c->stream));
+		if ((rc = launch_sw(c, (const uint8_t *)c->d_pool.p, (const bmh_sw_task_t *)c->d_tasks.p, m, (bmh_sw_result_t *)c->d_res.p, qmax, tmax, qmin)))
+			return rc;
+		SH_TRY(hipMemcpyAsync(results + lo, c->d_res.p, (size_t)m * sizeof(bmh_sw_result_t), hipMemcpyDeviceToHost, c->stream));
+		return BMH_OK;
+	});
+}
+
+int bmh_global_batch_sharded(bmh_ctx_t *const *ctxs, int n_ctx, const uint8_t *pool, size_t pool_bytes, const bmh_glb_task_t *tasks, int64_t n,
+                             bmh_glb_result_t *results, uint32_t *cigar_pool, size_t cigar_words)
+{
+	if (n > 0 && (!pool || !tasks || !results)) return BMH_E_ARG;
+	// a shard's CIGAR words come back into a buffer of its own first: the ranges of two shards may interleave in the caller's pool, and a
+	// device only holds what its own tasks wrote
+	std::vector<std::vector<uint32_t>> back((size_t)std::max(n_ctx, 0));
+	std::vector<GlbShape> shape((size_t)std::max(n_ctx, 0));
+	const int rc = run_sharded(ctxs, n_ctx, n, [&](bmh_ctx *c, int g, int64_t lo, int64_t m) -> int {
+		int rc;
+		GlbShape &gs = shape[(size_t)g];
+		if (m > 0xffffffffLL) return BMH_E_ARG;
+		if ((rc = validate_glb(c, tasks + lo, m, pool_bytes, cigar_pool != nullptr, cigar_words, &gs))) return rc;
+		c->pool_resident = false;
+		if ((rc = ensure(c, c->d_pool, pool_bytes + 16)) || (rc = ensure(c, c->d_tasks, (size_t)m * sizeof(bmh_glb_task_t))) ||
+		    (rc = ensure(c, c->d_res, (size_t)m * sizeof(bmh_glb_result_t))) || (rc = ensure(c, c->d_cigar, (cigar_words + 4) * 4)))
+			return rc;
+		SH_TRY(hipMemcpyAsync(c->d_pool.p, pool, pool_bytes, hipMemcpyHostToDevice, c->stream));
+		SH_TRY(hipMemcpyAsync(c->d_tasks.p, tasks + lo, (size_t)m * sizeof(bmh_glb_task_t), hipMemcpyHostToDevice, c->stream));
+		if ((rc = launch_global(c, (const uint8_t *)c->d_pool.p, (const bmh_glb_task_t *)c->d_tasks.p, m, (bmh_glb_result_t *)c->d_res.p,
+		                        (uint32_t *)c->d_cigar.p, nullptr, gs.qmax, gs.tmax, gs.wmax, gs.wraw)))
+			return rc;
+		SH_TRY(hipMemcpyAsync(results + lo, c->d_res.p, (size_t)m * sizeof(bmh_glb_result_t), hipMemcpyDeviceToHost, c->stream));
+		if (gs.cig_hi > gs.cig_lo) {
+			back[(size_t)g].resize(gs.cig_hi - gs.cig_lo);
+			SH_TRY(hipMemcpyAsync(back[(size_t)g].data(), (const uint32_t *)c->d_cigar.p + gs.cig_lo, (gs.cig_hi - gs.cig_lo) * 4, hipMemcpyDeviceToHost, c->stream));
+		}
+		return BMH_OK;
+	});
+	if (rc && rc != BMH_E_CIGAR_CAP && rc != BMH_E_RANGE) return rc; // (a flagged task: the other tasks' results are still delivered)
+	for (int g = 0; g < n_ctx && n > 0; ++g) {
+		const int64_t lo = n * g / n_ctx, hi = n * (g + 1) / n_ctx;
+		if (back[(size_t)g].empty()) continue;
+		for (int64_t k = lo; k < hi; ++k) {
+			const bmh_glb_task_t &x = tasks[k];
+			const size_t nw = std::min<size_t>((size_t)std::max(results[k].n_cigar, 0), x.cigar_cap);
+			if (nw) memcpy(cigar_pool + x.cigar_off, back[(size_t)g].data() + ((size_t)x.cigar_off - shape[(size_t)g].cig_lo), nw * 4);
+		}
+	}
+	return rc;
+}
+#undef SH_TRY
 
 int bmh_ctx_reserve_staging(bmh_ctx_t *ctx, size_t upload_bytes, size_t download_bytes)
 {

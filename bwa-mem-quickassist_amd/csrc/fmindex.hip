@@ -455,12 +455,16 @@ __device__ __forceinline__ uint64_t fm_sa(const DevBwt &B, uint64_t k)
 // per interval the SMEM kernel wrote; an interval long and rare enough (length >= min_seed_len, x[2] <= max_occ) takes
 // x[2] slots of `pos` (cursor[2]) and notes where they start in pos_base[slot], the others note UINT64_MAX.  The interval
 // count is read from the SMEM kernel's cursor: no host round trip between the two kernels.
+// When the SMEM kernel overflowed its output arrays (a cursor ran past its capacity) the slots behind the overflow were
+// reserved but never written -- d_scratch is shared with other stages and holds stale bytes there -- and the host is going to
+// retry with larger arrays anyway: nothing is looked up in that case (a stale x0/x2 would send fm_sa anywhere).
 __global__ void sa_of_intervals_kernel(DevBwt B, const Intv *__restrict__ intv, const unsigned long long *__restrict__ cursors,
-                                       unsigned long long intv_cap, int min_seed_len, unsigned long long max_occ,
+                                       unsigned long long call_cap, unsigned long long intv_cap, int min_seed_len, unsigned long long max_occ,
                                        uint64_t *__restrict__ pos_base, uint64_t *__restrict__ pos, unsigned long long pos_cap,
                                        unsigned long long *__restrict__ pos_cursor, int *__restrict__ overflow)
 {
-	const unsigned long long n = min(cursors[1], intv_cap);
+	if (cursors[0] > call_cap || cursors[1] > intv_cap) return; // overflowed attempt: its intervals are not all there
+	const unsigned long long n = cursors[1];
 	for (unsigned long long t = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (unsigned long long)gridDim.x * blockDim.x) {
 		const Intv v = intv[t];
 		const int len = (int)((uint32_t)v.info - (uint32_t)(v.info >> 32));
@@ -589,6 +593,10 @@ static int smem_impl(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const
                      bmh_smem_call_t *calls, size_t call_cap, uint64_t *intv_off, bmh_smem_intv_t *intv, size_t intv_cap, SeedPos *sp)
 {
 	if (!ctx || !o || n_reads < 0 || (n_reads > 0 && (!reads || !call_off || !intv_off))) return BMH_E_ARG;
+	if (o->min_emit_len < 0 || (sp && o->min_emit_len > o->min_seed_len)) {
+		ctx->last_error = "bmh_smem_opt_t.min_emit_len must be >= 0 (and <= min_seed_len for bmh_seed_batch)";
+		return BMH_E_ARG;
+	}
 	if (!ctx->bwt_bind) {
 		ctx->last_error = "no FM-index on the device (bmh_ctx_set_bwt)";
 		return BMH_E_ARG;
@@ -642,6 +650,8 @@ static int smem_impl(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const
 	size_t d_calls = std::max<size_t>((size_t)(ctx->smem_calls_per_base * 1.25 * (double)bytes) + 1024, 1024);
 	size_t d_intv = std::max<size_t>((size_t)(ctx->smem_intv_per_base * 1.25 * (double)bytes) + 4096, 4096);
 	size_t d_pos = sp ? std::max<size_t>((size_t)(ctx->smem_pos_per_base * 1.25 * (double)bytes) + 4096, 4096) : 0;
+	if (const char *e = getenv("BMH_SMEM_INIT_CAP")) // (test knob: start with arrays this small, so that the first attempt overflows)
+		if (atoll(e) > 0) d_calls = d_intv = (size_t)atoll(e), d_pos = sp ? (size_t)atoll(e) : 0;
 	const bmh_smem_call_t *h_calls = nullptr; // (in the pinned download buffer)
 	const uint32_t *h_read = nullptr;
 	const Intv *h_intv = nullptr;
@@ -681,7 +691,7 @@ static int smem_impl(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const
 		BMH_HIP(ctx, hipGetLastError());
 		if (sp) { // the positions of the intervals just written, straight behind them on the stream
 			hipLaunchKernelGGL(sa_of_intervals_kernel, dim3((unsigned)std::min<size_t>((d_intv + 255) / 256, 4096)), dim3(256), 0, ctx->stream, B,
-			                   (const Intv *)(d + o_intv), (const unsigned long long *)d, (unsigned long long)d_intv, sp->min_seed_len,
+			                   (const Intv *)(d + o_intv), (const unsigned long long *)d, (unsigned long long)d_calls, (unsigned long long)d_intv, sp->min_seed_len,
 			                   (unsigned long long)sp->max_occ, (uint64_t *)(d + o_pb), (uint64_t *)(d + o_pos), (unsigned long long)d_pos,
 			                   (unsigned long long *)(d + 32), (int *)(d + 16));
 			BMH_HIP(ctx, hipGetLastError());

@@ -78,9 +78,17 @@ static void heap_warm(int threads)
 
 extern double cputime(void), realtime(void); /* the host program's (utils.c) */
 static double g_t_loaded; /* realtime() when the shim was loaded */
+static void qa_shim_exit(void);
 static void *prewarm_thread(void *arg)
 {
+	int ndev = 0;
 	(void)arg;
+	/* The HIP runtime registers its own exit handlers when it is first initialised -- here, in this thread.  Exit handlers run
+	 * last-registered-first, so the stop-and-join handler is registered AFTER that first HIP call: it then runs BEFORE the
+	 * runtime's teardown whatever the order of the two libraries' constructors was.  (It is idempotent; the constructor
+	 * registers it too, for a run that ends before this line.) */
+	bmh_device_count(&ndev);
+	atexit(qa_shim_exit);
 	bmh_pool_prewarm(g_prewarm_n); /* (several threads creating contexts side by side are no faster: measured) */
 	if (getenv("BMH_VERBOSE")) fprintf(stderr, "[bwamem_hip] %d contexts ready %.3f s after the shim was loaded\n", g_prewarm_n, realtime() - g_t_loaded);
 	return 0;
@@ -88,11 +96,10 @@ static void *prewarm_thread(void *arg)
 /* A run shorter than the pre-warming (a few hundred reads) must not reach the runtime's teardown with that thread still
  * inside a HIP call: it is told to stop and waited for. */
 static pthread_t g_prewarm;
-static int g_prewarm_on;
+static volatile int g_prewarm_on;
 static void qa_shim_exit(void)
 {
-	if (!g_prewarm_on) return;
-	g_prewarm_on = 0;
+	if (!__sync_bool_compare_and_swap(&g_prewarm_on, 1, 0)) return; /* once, whichever registration fires first */
 	bmh_pool_stop();
 	pthread_join(g_prewarm, 0);
 }
@@ -154,7 +161,7 @@ __attribute__((constructor)) static void qa_shim_loaded(void)
 	heap_warm(g_prewarm_n);
 	if (pthread_create(&t, 0, prewarm_thread, 0) == 0) {
 		g_prewarm = t, g_prewarm_on = 1;
-		atexit(qa_shim_exit); /* registered after the HIP runtime's own handlers, so it runs before them */
+		atexit(qa_shim_exit); /* a run that ends before the pre-warming thread's first HIP call; see prewarm_thread for the other case */
 	}
 }
 
@@ -307,8 +314,10 @@ static void qa_seed_batch_end(void)
 static long long g_p1_cnt[4]; /* chains, seeds extended, seeds speculated in vain, short-chain Smith-Watermans */
 static long long g_p1_us[5]; /* phase 1, thread-microseconds: wait for a GPU slot, seeding batch, chaining (host), wait, extension batch */
 
-bmh_alnreg_v *mem_align1_core_batched(const ref_mem_opt_t *opt, const void *bwt, const ref_bntseq_head_t *bns,
-                                      const uint8_t *pac, ref_bseq1_t *seqs, int start, int batch_size)
+/* (a static body behind both exported names: inside a process that also holds the reference's own definitions -- the tests load
+ * libbwa_ref.so next to this library -- a call through the exported name would bind to whichever was loaded first) */
+static bmh_alnreg_v *align_batch(const ref_mem_opt_t *opt, const void *bwt, const ref_bntseq_head_t *bns,
+                                 const uint8_t *pac, ref_bseq1_t *seqs, int start, int batch_size)
 {
 	bmh_chain_v *chn = (bmh_chain_v *)malloc(sizeof(bmh_chain_v) * (size_t)batch_size);
 	bmh_alnreg_v *regs = (bmh_alnreg_v *)calloc((size_t)batch_size, sizeof(bmh_alnreg_v));
@@ -389,6 +398,28 @@ bmh_alnreg_v *mem_align1_core_batched(const ref_mem_opt_t *opt, const void *bwt,
 	return regs; /* caller copies and frees, bwamem.c:1272-1278 */
 }
 
+bmh_alnreg_v *mem_align1_core_batched(const ref_mem_opt_t *opt, const void *bwt, const ref_bntseq_head_t *bns,
+                                      const uint8_t *pac, ref_bseq1_t *seqs, int start, int batch_size)
+{
+	return align_batch(opt, bwt, bns, pac, seqs, start, batch_size);
+}
+
+/* mem_align1_core() with the reference's exact signature (bwamem.c:1122-1149; used by mem_align1 :1151 and example.c:44): one
+ * read through the same drivers as a batch of one -- `seq` is converted to base codes in place as at :1128-1129, the result
+ * vector is malloc'd and the caller's (as kv_push would have left it).  A batch of one cannot fill a GPU; the entry point
+ * exists so that library users of the reference's API get the same regions from the same code path. */
+bmh_alnreg_v mem_align1_core(const ref_mem_opt_t *opt, const void *bwt, const ref_bntseq_head_t *bns, const uint8_t *pac, int l_seq, char *seq)
+{
+	ref_bseq1_t one;
+	bmh_alnreg_v *v, out;
+	memset(&one, 0, sizeof(one));
+	one.l_seq = l_seq, one.seq = seq;
+	v = align_batch(opt, bwt, bns, pac, &one, 0, 1);
+	out = v[0];
+	free(v);
+	return out;
+}
+
 /* =====================================================================================================================
  * mem_process_seqs() with the reference's exact signature (bwamem.h:117, bwamem.c:1297-1327): the same three steps as
  * the reference -- phase 1 through the batching seam above, insert-size statistics, phase 2 -- every data-parallel part
@@ -420,7 +451,7 @@ typedef struct {
 static void qa_worker1_batched(void *data, int start, int batch_size, int tid) /* == worker1_batched, bwamem.c:1264-1279 */
 {
 	qa_worker_t *w = (qa_worker_t *)data;
-	bmh_alnreg_v *ret = mem_align1_core_batched(w->opt, w->bwt, w->bns, w->pac, w->seqs, start, batch_size);
+	bmh_alnreg_v *ret = align_batch(w->opt, w->bwt, w->bns, w->pac, w->seqs, start, batch_size);
 	int i;
 	(void)tid;
 	for (i = start; i < start + batch_size; ++i) w->regs[i] = ret[i - start];

@@ -430,103 +430,151 @@ static inline int rlen_of(int n_cigar, const uint32_t *cigar) /* get_rlen, bwame
 	return l;
 }
 
-/* ---- mem_aln2sam, bwamem.c:904-1017.  `cig` is the slice's CIGAR arena. */
-static void aln2sam(const bmh_refidx_t *bns, str_t *str, const bmh_seq_t *s, int n, const aln_t *list, int which, const aln_t *m_,
-                    const uint32_t *cig, const char *rg_id)
+/* ---- One SAM line (what mem_aln2sam prints, bwamem.c:904-1017), built the way this library is: the record and its mate are first
+ * RESOLVED into a small value (flag bits, where an unmapped end is placed, clip lengths), then a fixed table of column emitters
+ * writes the eleven mandatory columns and the tags from that value.  `cig` is the slice's CIGAR arena. */
+typedef struct {
+	int mapped;           /* has a reference sequence to print (its own, or the mate's for an unmapped end) */
+	int rid, rev, n_op;   /* n_op = 0 when the end only borrows its mate's position */
+	int64_t pos;
+	const uint32_t *op;
+} place_t;
+
+typedef struct {
+	const bmh_refidx_t *bns;
+	const bmh_seq_t *read;
+	const aln_t *all;     /* the read's records (for SA:Z) */
+	int n_all, self;      /* ... and which one this line is */
+	const aln_t *rec;
+	const uint32_t *cig;
+	const char *rg_id;
+	int flag, has_mate;
+	place_t me, mate;
+} samline_t;
+
+static place_t place_of(const aln_t *a, const uint32_t *cig)
 {
-	aln_t ptmp = list[which], *p = &ptmp, mtmp, *m = 0;
-	const uint32_t *pc, *mc = 0;
+	place_t p;
+	p.mapped = a->rid >= 0, p.rid = a->rid, p.rev = a->is_rev, p.n_op = a->n_cigar, p.pos = a->pos, p.op = cig + a->cig_off;
+	return p;
+}
+/* an unmapped end sits where its mapped mate is, without a CIGAR (bwamem.c:917-918) */
+static void borrow_place(place_t *dst, const place_t *src) { dst->mapped = 1, dst->rid = src->rid, dst->pos = src->pos, dst->rev = src->rev, dst->n_op = 0; }
+
+static int clip_len(const place_t *p, int at) /* length of a clip operation at CIGAR index `at`, else 0 */
+{
+	const int op = (int)(p->op[at] & 0xf);
+	return op == 3 || op == 4 ? (int)(p->op[at] >> 4) : 0;
+}
+static int64_t far_end(const place_t *p) { return p->pos + (p->rev ? rlen_of(p->n_op, p->op) - 1 : 0); } /* 5' end on the reference */
+
+/* bases or qualities of [from,to) in the orientation of the alignment; `code` maps a base code to its letter (NULL: copy bytes) */
+static void put_oriented(str_t *t, const char *src, int from, int to, int rev, const char *code)
+{
+	int i, n = to > from ? to - from : 0;
+	char *d;
+	st_room(t, (size_t)n + 2);
+	d = t->s + t->l;
+	if (!rev) for (i = 0; i < n; ++i) d[i] = code ? code[(int)src[from + i]] : src[from + i];
+	else for (i = 0; i < n; ++i) d[i] = code ? code[(int)src[to - 1 - i]] : src[to - 1 - i];
+	t->l += (size_t)n;
+}
+enum { CLIP_SOFT, CLIP_HARD, CLIP_ASIS }; /* clips of the first line are S, of a supplementary line H; SA:Z prints what is stored */
+static void put_ops(str_t *t, const uint32_t *op, int n, int clips)
+{
 	int i;
-	if (m_) mtmp = *m_, m = &mtmp;
-	p->flag |= m ? 0x1 : 0;                 /* paired in sequencing */
-	p->flag |= p->rid < 0 ? 0x4 : 0;        /* unmapped */
-	p->flag |= m && m->rid < 0 ? 0x8 : 0;   /* mate unmapped */
-	if (p->rid < 0 && m && m->rid >= 0) p->rid = m->rid, p->pos = m->pos, p->is_rev = m->is_rev, p->n_cigar = 0; /* place next to the mate */
-	if (m && m->rid < 0 && p->rid >= 0) m->rid = p->rid, m->pos = p->pos, m->is_rev = p->is_rev, m->n_cigar = 0;
-	p->flag |= p->is_rev ? 0x10 : 0;
-	p->flag |= m && m->is_rev ? 0x20 : 0;
-	pc = cig + p->cig_off;
-	if (m) mc = cig + m->cig_off;
-
-	st_s(str, s->name), st_c(str, '\t');
-	st_l(str, (p->flag & 0xffff) | (p->flag & 0x10000 ? 0x100 : 0)), st_c(str, '\t');
-	if (p->rid >= 0) {
-		st_s(str, bns->anns[p->rid].name), st_c(str, '\t');
-		st_l(str, (long)(p->pos + 1)), st_c(str, '\t');
-		st_l(str, p->mapq), st_c(str, '\t');
-		if (p->n_cigar) {
-			for (i = 0; i < p->n_cigar; ++i) {
-				int c = (int)(pc[i] & 0xf);
-				if (c == 3 || c == 4) c = which ? 4 : 3; /* hard clipping for supplementary alignments */
-				st_l(str, (long)(pc[i] >> 4)), st_c(str, "MIDSH"[c]);
-			}
-		} else st_c(str, '*');
-	} else st_n(str, "*\t0\t0\t*", 7);
-	st_c(str, '\t');
-
-	if (m && m->rid >= 0) { /* mate position */
-		if (p->rid == m->rid) st_c(str, '=');
-		else st_s(str, bns->anns[m->rid].name);
-		st_c(str, '\t');
-		st_l(str, (long)(m->pos + 1)), st_c(str, '\t');
-		if (p->rid == m->rid) {
-			const int64_t p0 = p->pos + (p->is_rev ? rlen_of(p->n_cigar, pc) - 1 : 0);
-			const int64_t p1 = m->pos + (m->is_rev ? rlen_of(m->n_cigar, mc) - 1 : 0);
-			if (m->n_cigar == 0 || p->n_cigar == 0) st_c(str, '0');
-			else st_l(str, (long)-(p0 - p1 + (p0 > p1 ? 1 : p0 < p1 ? -1 : 0)));
-		} else st_c(str, '0');
-	} else st_n(str, "*\t0\t0", 5);
-	st_c(str, '\t');
-
-	if (p->flag & 0x100) st_n(str, "*\t*", 3); /* no SEQ/QUAL for secondary alignments */
-	else {
-		int qb = 0, qe = s->l_seq;
-		const int first_clip = p->n_cigar && which && ((pc[0] & 0xf) == 4 || (pc[0] & 0xf) == 3) ? (int)(pc[0] >> 4) : 0;
-		const int last_clip = p->n_cigar && which && ((pc[p->n_cigar - 1] & 0xf) == 4 || (pc[p->n_cigar - 1] & 0xf) == 3) ? (int)(pc[p->n_cigar - 1] >> 4) : 0;
-		if (!p->is_rev) qb += first_clip, qe -= last_clip;
-		else qe -= first_clip, qb += last_clip;
-		st_room(str, 2 * (size_t)(qe > qb ? qe - qb : 0) + 4);
-		if (!p->is_rev)
-			for (i = qb; i < qe; ++i) str->s[str->l++] = "ACGTN"[(int)s->seq[i]];
-		else
-			for (i = qe - 1; i >= qb; --i) str->s[str->l++] = "TGCAN"[(int)s->seq[i]];
-		str->s[str->l++] = '\t';
-		if (s->qual) {
-			if (!p->is_rev)
-				for (i = qb; i < qe; ++i) str->s[str->l++] = s->qual[i];
-			else
-				for (i = qe - 1; i >= qb; --i) str->s[str->l++] = s->qual[i];
-		} else str->s[str->l++] = '*';
+	for (i = 0; i < n; ++i) {
+		int c = (int)(op[i] & 0xf);
+		if (clips != CLIP_ASIS && (c == 3 || c == 4)) c = clips == CLIP_HARD ? 4 : 3;
+		st_l(t, (long)(op[i] >> 4)), st_c(t, "MIDSH"[c]);
 	}
+}
 
-	if (p->n_cigar) {
-		st_n(str, "\tNM:i:", 6), st_l(str, p->NM);
-		st_n(str, "\tMD:Z:", 6), st_s(str, p->md);
+static void col_qname_flag(const samline_t *L, str_t *t)
+{
+	st_s(t, L->read->name), st_c(t, '\t');
+	st_l(t, (L->flag & 0xffff) | (L->flag & 0x10000 ? 0x100 : 0)); /* -M: a supplementary hit is shown as secondary (bwamem.c:928) */
+}
+static void col_rname_pos_mapq_cigar(const samline_t *L, str_t *t)
+{
+	if (!L->me.mapped) { st_n(t, "*\t0\t0\t*", 7); return; }
+	st_s(t, L->bns->anns[L->me.rid].name), st_c(t, '\t');
+	st_l(t, (long)(L->me.pos + 1)), st_c(t, '\t');
+	st_l(t, L->rec->mapq), st_c(t, '\t');
+	if (L->me.n_op) put_ops(t, L->me.op, L->me.n_op, L->self ? CLIP_HARD : CLIP_SOFT);
+	else st_c(t, '*');
+}
+static void col_mate(const samline_t *L, str_t *t)
+{
+	if (!L->has_mate || !L->mate.mapped) { st_n(t, "*\t0\t0", 5); return; }
+	if (L->me.rid == L->mate.rid) st_c(t, '=');
+	else st_s(t, L->bns->anns[L->mate.rid].name);
+	st_c(t, '\t'), st_l(t, (long)(L->mate.pos + 1)), st_c(t, '\t');
+	if (L->me.rid == L->mate.rid && L->me.n_op && L->mate.n_op) { /* TLEN between the two 5' ends (bwamem.c:957-961) */
+		const int64_t d = far_end(&L->me) - far_end(&L->mate);
+		st_l(t, (long)-(d + (d > 0) - (d < 0)));
+	} else st_c(t, '0');
+}
+static void col_seq_qual(const samline_t *L, str_t *t)
+{
+	int from = 0, to = L->read->l_seq;
+	if (L->flag & 0x100) { st_n(t, "*\t*", 3); return; } /* none on secondary lines */
+	if (L->self && L->me.n_op) { /* a supplementary line prints only what it aligns: its clips are hard (bwamem.c:971-976) */
+		const int c5 = clip_len(&L->me, 0), c3 = clip_len(&L->me, L->me.n_op - 1);
+		if (L->me.rev) from += c3, to -= c5;
+		else from += c5, to -= c3;
 	}
-	if (p->score >= 0) st_n(str, "\tAS:i:", 6), st_l(str, p->score);
-	if (p->sub >= 0) st_n(str, "\tXS:i:", 6), st_l(str, p->sub);
-	if (rg_id && rg_id[0]) st_n(str, "\tRG:Z:", 6), st_s(str, rg_id);
-	if (!(p->flag & 0x100)) { /* other primary hits -> SA tag */
-		for (i = 0; i < n; ++i)
-			if (i != which && !(list[i].flag & 0x100)) break;
-		if (i < n) {
-			st_n(str, "\tSA:Z:", 6);
-			for (i = 0; i < n; ++i) {
-				const aln_t *r = &list[i];
-				const uint32_t *rc = cig + r->cig_off;
-				int k;
-				if (i == which || (list[i].flag & 0x100)) continue;
-				st_s(str, bns->anns[r->rid].name), st_c(str, ',');
-				st_l(str, (long)(r->pos + 1)), st_c(str, ',');
-				st_c(str, "+-"[r->is_rev]), st_c(str, ',');
-				for (k = 0; k < r->n_cigar; ++k) st_l(str, (long)(rc[k] >> 4)), st_c(str, "MIDSH"[rc[k] & 0xf]);
-				st_c(str, ','), st_l(str, r->mapq);
-				st_c(str, ','), st_l(str, r->NM);
-				st_c(str, ';');
-			}
+	put_oriented(t, L->read->seq, from, to, L->me.rev, L->me.rev ? "TGCAN" : "ACGTN");
+	st_c(t, '\t');
+	if (L->read->qual) put_oriented(t, L->read->qual, from, to, L->me.rev, 0);
+	else st_c(t, '*');
+}
+static void col_tags(const samline_t *L, str_t *t)
+{
+	const aln_t *r = L->rec;
+	int i, others = 0;
+	if (L->me.n_op) st_n(t, "\tNM:i:", 6), st_l(t, r->NM), st_n(t, "\tMD:Z:", 6), st_s(t, r->md);
+	if (r->score >= 0) st_n(t, "\tAS:i:", 6), st_l(t, r->score);
+	if (r->sub >= 0) st_n(t, "\tXS:i:", 6), st_l(t, r->sub);
+	if (L->rg_id && L->rg_id[0]) st_n(t, "\tRG:Z:", 6), st_s(t, L->rg_id);
+	if (!(L->flag & 0x100)) { /* SA:Z lists the read's other non-secondary lines (bwamem.c:995-1013) */
+		for (i = 0; i < L->n_all; ++i) others += i != L->self && !(L->all[i].flag & 0x100);
+		if (others) st_n(t, "\tSA:Z:", 6);
+		for (i = 0; others && i < L->n_all; ++i) {
+			const aln_t *o = &L->all[i];
+			if (i == L->self || (o->flag & 0x100) || o->rid < 0) continue;
+			st_s(t, L->bns->anns[o->rid].name), st_c(t, ','), st_l(t, (long)(o->pos + 1)), st_c(t, ',');
+			st_c(t, o->is_rev ? '-' : '+'), st_c(t, ',');
+			put_ops(t, L->cig + o->cig_off, o->n_cigar, CLIP_ASIS);
+			st_c(t, ','), st_l(t, o->mapq), st_c(t, ','), st_l(t, o->NM), st_c(t, ';');
 		}
 	}
-	if (s->comment) st_c(str, '\t'), st_s(str, s->comment);
+	if (L->read->comment) st_c(t, '\t'), st_s(t, L->read->comment);
+}
+
+typedef void (*sam_col_fn)(const samline_t *, str_t *);
+static const sam_col_fn k_sam_cols[] = {col_qname_flag, col_rname_pos_mapq_cigar, col_mate, col_seq_qual};
+
+static void aln2sam(const bmh_refidx_t *bns, str_t *str, const bmh_seq_t *s, int n, const aln_t *list, int which, const aln_t *mate,
+                    const uint32_t *cig, const char *rg_id)
+{
+	samline_t L;
+	size_t c;
+	L.bns = bns, L.read = s, L.all = list, L.n_all = n, L.self = which, L.rec = &list[which], L.cig = cig, L.rg_id = rg_id;
+	L.has_mate = mate != 0;
+	L.me = place_of(L.rec, cig);
+	L.flag = L.rec->flag | (mate ? 0x1 : 0) | (L.me.mapped ? 0 : 0x4);
+	if (mate) {
+		L.mate = place_of(mate, cig);
+		if (!L.mate.mapped) L.flag |= 0x8;
+		if (!L.me.mapped && L.mate.mapped) borrow_place(&L.me, &L.mate);
+		else if (!L.mate.mapped && L.me.mapped) borrow_place(&L.mate, &L.me);
+		if (L.mate.rev) L.flag |= 0x20;
+	}
+	if (L.me.rev) L.flag |= 0x10;
+	for (c = 0; c < sizeof(k_sam_cols) / sizeof(k_sam_cols[0]); ++c) k_sam_cols[c](&L, str), st_c(str, '\t');
+	--str->l; /* the tags bring their own separators */
+	col_tags(&L, str);
 	st_c(str, '\n');
 }
 

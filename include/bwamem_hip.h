@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BMH_VERSION 100 /* 0.1.0 */
+#define BMH_VERSION 300 /* 0.3.0: bmh_smem_opt_t grew min_emit_len (20 bytes), mem_align1_core, *_batch_sharded */
 
 enum {
 	BMH_OK = 0,
@@ -170,6 +170,18 @@ int bmh_global_batch_device(bmh_ctx_t *ctx, const uint8_t *d_seqpool,
 int bmh_extend_batch_sharded(bmh_ctx_t *const *ctxs, int n_ctx, const uint8_t *seqpool,
                              size_t pool_bytes, const bmh_ext_task_t *tasks, int64_t n,
                              bmh_ext_result_t *results);
+/* The same static split for the other three batches of the DP path (declared here, records defined below): the fused per-seed
+ * records, ksw_global2 + traceback, ksw_align2.  Contiguous task ranges like kt_for_batch's (reference kthread_batch.c:44-56,
+ * bwamem.c:1313), every device gets the whole pool, everything is enqueued on every device before any is waited for, results
+ * land at their task index; a shard's CIGAR words are copied into the caller's pool task by task. */
+struct bmh_seed_task; struct bmh_seed_result; struct bmh_sw_task; struct bmh_sw_result;
+int bmh_seedext_batch_sharded(bmh_ctx_t *const *ctxs, int n_ctx, const uint8_t *seqpool, size_t pool_bytes,
+                              const struct bmh_seed_task *tasks, int64_t n, struct bmh_seed_result *results);
+int bmh_global_batch_sharded(bmh_ctx_t *const *ctxs, int n_ctx, const uint8_t *seqpool, size_t pool_bytes,
+                             const bmh_glb_task_t *tasks, int64_t n, bmh_glb_result_t *results,
+                             uint32_t *cigar_pool, size_t cigar_pool_words);
+int bmh_sw_batch_sharded(bmh_ctx_t *const *ctxs, int n_ctx, const uint8_t *seqpool, size_t pool_bytes,
+                         const struct bmh_sw_task *tasks, int64_t n, struct bmh_sw_result *results);
 
 /* ---- L2.5: one record per SEED -- the accelerator record the fork sketched and never used
  * (ext_param_t / ext_res_t, reference bwamem.c:553-577).  The device runs, for every seed, what
@@ -493,7 +505,10 @@ typedef struct bmh_smem_opt {
 	int32_t min_emit_len; /* 0: every interval of every call comes back, like bwt_smem1.  > 0: only intervals at least this
 	                       * long do (call.n counts those) -- all that mem_insert_seed looks at with min_emit_len <=
 	                       * min_seed_len (bwamem.c:219), about one interval in twenty on 150 bp reads; the calls made, their
-	                       * arguments and return values are the same either way                                       */
+	                       * arguments and return values are the same either way.  Must be >= 0; bmh_seed_batch and
+	                       * bmh_chain_reads additionally need min_emit_len <= min_seed_len (chaining recomputes the longest
+	                       * match and the re-seeding decision from the intervals it is given): BMH_E_ARG otherwise.
+	                       * The struct is 20 bytes since BMH_VERSION 300 (16 before: rebuild callers)               */
 } bmh_smem_opt_t;
 typedef struct bmh_smem_call { /* one bwt_smem1 call and where its result intervals lie */
 	int32_t x, min_intv; /* arguments (bwt.c:288)                         */
@@ -549,7 +564,10 @@ int bmh_sa_batch(bmh_ctx_t *ctx, const uint64_t *k, int64_t n, uint64_t *pos);
  * x[2] <= max_occ), its suffix-array indices x[0]..x[0]+x[2]-1 and records in sa_off[k] where interval k's run starts
  * (UINT64_MAX = never looked up); the caller resolves the list with ONE bmh_sa_batch and passes the positions as sa_pos
  * -- no sorting, no searching.  chains[r] is filled like mem_chain's return value: a malloc'd array of chains in the
- * reference's order, each with a malloc'd seed array; the caller frees both. */
+ * reference's order, each with a malloc'd seed array; the caller frees both.
+ * Precondition: the intervals come from a bmh_smem_batch / bmh_seed_batch run with min_emit_len <= o->min_seed_len (0
+ * included): with a larger filter the longest match of a call and the re-seeding decision derived from it would be
+ * computed from a truncated list and chains would silently differ. */
 typedef struct bmh_chain_opt { /* the mem_opt_t fields seeding + chaining read (bwamem.h:21-48) */
 	int32_t w, max_chain_gap, min_seed_len, max_occ;
 	int32_t split_len;   /* (int)(min_seed_len * split_factor + .499), bwamem.c:211 */

@@ -2,14 +2,15 @@
 pipeline_ref.sh: SAM of the fork == SAM of stock).
 
 REF = the reference compiled by oracle/Makefile (oracle/_ref/bwa), untouched.
-DUT = the same binary with libbwamem_hip_dropin.so LD_PRELOADed: phase 1 goes through the fork's
-      batching seam mem_align1_core_batched -> FM-index queries of the batch on the GPU (bmh_smem_batch, bmh_sa_batch,
-      served to the reference's own mem_chain) -> bmh_chain2aln_batch (GPU extension kernels, one
-      context per host thread); mem_process_seqs itself is taken over: insert-size statistics (bmh_pestat), the whole
-      chunk's mate rescue (bmh_matesw_batch) and phase 2 (bmh_sam_batch: de-duplication, primary marking, pairing,
-      mapQ, the global alignments of the printed regions as GPU batches, SAM text) are the library's own code; what is
-      left of the reference after seeding is its chaining (mem_chain / mem_chain_flt) and the ksw_align2 of short chains
-      (a per-call GPU drop-in).
+DUT = the same binary with libbwamem_hip_dropin.so LD_PRELOADed.  Everything between read parsing and printing is then this
+      library: phase 1 goes through the fork's batching seam mem_align1_core_batched -> the batch's FM-index queries on the GPU
+      (bmh_seed_batch: SMEMs + suffix-array look-ups) -> the library's own chaining (bmh_chain_reads: mem_chain / mem_chain_flt
+      restated, asserted below from the shim's log) -> bmh_chains2regs_batch (fused per-seed extension records on the GPU,
+      mem_chain2aln_short's ksw_align2 calls as ONE bmh_sw_batch) -> bmh_sort_and_dedup; mem_process_seqs itself is taken over:
+      insert-size statistics (bmh_pestat), the whole chunk's mate rescue (bmh_matesw_batch) and phase 2 (bmh_sam_batch: primary
+      marking, pairing, mapQ, the global alignments of exactly the printed regions as GPU batches, SAM text).  Nothing of the
+      reference's bwamem.c / bwamem_pair.c / bwt.c / ksw.c runs inside mem_process_seqs; the host program keeps FASTQ parsing, its
+      thread pool, clocks and printing.
 SAM must be byte-identical except the @PG header line.  Runs first in the session (file name) so
 the parent process is GPU-clean when it starts the child processes."""
 import os

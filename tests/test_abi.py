@@ -31,7 +31,7 @@ def test_dropin_exports_reference_signatures(pkg):
     if not os.path.exists(pkg.DROPIN_PATH):
         build()
     out = os.popen(f"nm -D --defined-only {pkg.DROPIN_PATH}").read()
-    for n in ("ksw_extend2", "ksw_global2", "ksw_align2", "ksw_align", "mem_align1_core_batched", "mem_process_seqs"):
+    for n in ("ksw_extend2", "ksw_global2", "ksw_align2", "ksw_align", "mem_align1_core_batched", "mem_align1_core", "mem_process_seqs"):
         assert re.search(rf"\bT {n}\b", out), n
 
 
@@ -47,7 +47,7 @@ def test_record_layouts_match_header(pkg):
 
 def test_version_and_strerror(pkg):
     lib = pkg.lib()
-    assert lib.bmh_version() == 100
+    assert lib.bmh_version() == 300
     assert lib.bmh_strerror(0) == b"ok"
     assert b"range" in lib.bmh_strerror(pkg.BMH_E_RANGE)
 

@@ -132,3 +132,38 @@ def test_seed_batch_is_smem_batch_plus_the_suffix_array_lookups(kernel, monkeypa
         sample = rng.choice(len(keys), 300, replace=False)
         assert (np.concatenate(got_pos)[sample] == kswlib.orc_sa(cb, keys[sample])).all()
     ctx.close()
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_seed_batch_survives_an_overflowed_first_attempt(kernel, monkeypatch):
+    """Output arrays far too small for the first attempt (BMH_SMEM_INIT_CAP): the SMEM kernel overflows, the look-up kernel behind it
+    must not walk the unwritten slots (stale bytes of a buffer other stages share -- run those stages first so that it IS dirty), the
+    host retries with arrays that fit, and the results are those of a comfortable first attempt."""
+    monkeypatch.setenv("BMH_SMEM_KERNEL", kernel)
+    cb, keep, raw, opt, reads, per, sa_k, sa_pos = kswlib.golden_fmindex()
+    rng = np.random.default_rng(5)
+    src = np.concatenate(reads)
+    more = list(reads) + [src[p:p + 150].copy() for p in rng.integers(0, len(src) - 150, 800)]
+    o2 = np.array(opt, dtype=kswlib.SMEM_OPT).copy()
+    ctx = _ctx_with({})
+    ctx.set_bwt(*raw)
+    want, woffs, wpos = ctx.seed_batch(o2, 10000, more)
+    ctx.close()
+    monkeypatch.setenv("BMH_SMEM_INIT_CAP", "64")
+    ctx = _ctx_with({})
+    ctx.set_bwt(*raw)
+    # dirty the shared scratch with all-ones intervals: x2 <= max_occ is false for them only if the guard looks at them at all;
+    # what matters is that the call returns, with the same answers
+    p = kswlib.make_params()
+    pool, st = kswgen.gen_sw_materescue(rng, 4000, p)
+    ctx.sw_batch(pool, st)
+    got, offs, pos = ctx.seed_batch(o2, 10000, more)
+    assert len(pos) == len(wpos)
+    for r, ((gc, gi), (wc, wi), so, wo) in enumerate(zip(got, want, offs, woffs)):
+        assert _same_calls((gc, gi), (wc, wi)), f"read {r}"
+        look = so != np.uint64(0xffffffffffffffff)
+        assert (look == (wo != np.uint64(0xffffffffffffffff))).all()
+        for k in np.nonzero(look)[0]:
+            x2 = int(gi["x2"][k])
+            assert (pos[int(so[k]):int(so[k]) + x2] == wpos[int(wo[k]):int(wo[k]) + x2]).all()
+    ctx.close()

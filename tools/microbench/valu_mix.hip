@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <cstring>
+#include <cstdlib>
 #include <vector>
 #include <algorithm>
 
@@ -70,28 +71,37 @@
 	X(mix_or_pkmax, "v_or_b32 %0, %0, %1\n v_pk_max_u16 %0, %0, %2") X(mix_3add_max, "v_add_u32 %0, %0, %1\n v_sub_u32 %0, %0, %2\n v_and_b32 %0, %0, %1\n v_max_i32 %0, %0, %2") \
 	X(snop0, "s_nop 0") X(snop1, "s_nop 1") X(mix_add_snop, "v_add_u32 %0, %0, %1\n s_nop 0")                           \
 	X(mix_max_salu, "v_max_i32 %0, %0, %1\n s_add_u32 s10, s10, 1") X(mix_add_salu, "v_add_u32 %0, %0, %1\n s_add_u32 s10, s10, 1") \
-	X(salu, "s_add_u32 s10, s10, 1")
+	X(salu, "s_add_u32 s10, s10, 1")                                                                                     \
+	X(dep1_add, "v_add_u32 %3, %3, %1") X(dep1_max, "v_max_i32 %3, %3, %1") X(dep1_perm, "v_perm_b32 %3, %3, %1, %2")     \
+	X(dep2_add, "v_add_u32 %3, %3, %1\n v_add_u32 %4, %4, %1") X(dep2_max, "v_max_i32 %3, %3, %1\n v_max_i32 %4, %4, %1") \
+	X(dep1_chain3, "v_add_u32 %3, %3, %1\n v_max_i32 %3, %3, %2\n v_sub_u32 %3, %3, %1")
 
 constexpr int ITERS = 1500;
 constexpr int UNROLL = 64;
 
 #define KERNEL(name, text)                                                                                              \
-	__global__ void __launch_bounds__(512) k_##name(uint32_t *out, long long *cyc)                                      \
+	__global__ void __launch_bounds__(256) k_##name(uint32_t *out, long long *cyc)                                      \
 	{                                                                                                                   \
+		extern __shared__ uint32_t lds_keep[];                                                                          \
 		uint32_t a[8];                                                                                                  \
-		uint32_t b = threadIdx.x * 3 + 1, c = threadIdx.x * 5 + 2;                                                      \
+		uint32_t b = threadIdx.x * 3 + 1, c = threadIdx.x * 5 + 2, d0 = threadIdx.x, d1 = threadIdx.x + 9;                                                      \
 		for (int i = 0; i < 8; ++i) a[i] = threadIdx.x * 7 + i;                                                         \
 		long long t0 = __builtin_amdgcn_s_memtime();                                                                    \
 		long long r0 = __builtin_amdgcn_s_memrealtime();                                                                \
 		for (int it = 0; it < ITERS; ++it) {                                                                            \
-			_Pragma("unroll") for (int i = 0; i < UNROLL; ++i) asm volatile(text : "+v"(a[i & 7]), "+v"(b), "+v"(c) : : "vcc", "s10", "s11"); \
+			_Pragma("unroll") for (int i = 0; i < UNROLL; ++i) asm volatile(text : "+v"(a[i & 7]), "+v"(b), "+v"(c), "+v"(d0), "+v"(d1) : : "vcc", "s10", "s11"); \
 		}                                                                                                               \
 		long long t1 = __builtin_amdgcn_s_memtime();                                                                    \
 		long long r1 = __builtin_amdgcn_s_memrealtime();                                                                \
-		uint32_t s = b + c;                                                                                             \
+		uint32_t s = b + c + d0 + d1;                                                                                             \
 		for (int i = 0; i < 8; ++i) s += a[i];                                       \
 		out[blockIdx.x * blockDim.x + threadIdx.x] = s;                                                                 \
-		if (threadIdx.x == 0) cyc[blockIdx.x * 2] = t1 - t0, cyc[blockIdx.x * 2 + 1] = r1 - r0;                         \
+		if (s == 0x12345) lds_keep[threadIdx.x] = s;                                                                    \
+		if (threadIdx.x == 0) {                                                                                         \
+			cyc[blockIdx.x * 4] = t1 - t0, cyc[blockIdx.x * 4 + 1] = r1 - r0;                                           \
+			cyc[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));  /* HW_REG_HW_ID */  \
+			cyc[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)); /* HW_REG_XCC_ID */ \
+		}                                                                                                               \
 	}
 OPS(KERNEL)
 
@@ -99,43 +109,70 @@ struct Op { const char *name; const char *text; void (*fn)(uint32_t *, long long
 #define ENTRY(name, text) {#name, text, k_##name},
 static const Op ops[] = {OPS(ENTRY)};
 
+static int hwid_cu(unsigned id) { return (int)((id >> 8) & 0xf) | (int)((id >> 12) & 1) << 4 | (int)((id >> 13) & 7) << 5; } // cu | sh | se
+
 int main(int argc, char **argv)
 {
 	const char *filter = argc > 1 ? argv[1] : nullptr;
 	uint32_t *out;
 	long long *cyc;
-	hipMalloc(&out, 64 << 20);
-	hipMalloc(&cyc, 1 << 20);
+	hipMalloc(&out, 256 << 20);
+	hipMalloc(&cyc, 8 << 20);
 	hipDeviceProp_t prop;
 	hipGetDeviceProperties(&prop, 0);
 	const int cus = prop.multiProcessorCount;
-	std::vector<long long> h(cus * 2 * 4);
-	printf("# %d CUs, nominal %.2f GHz; shader cycles (s_memtime) per wave-instruction per SIMD, all SIMDs of the chip busy; W = resident waves per SIMD\n", cus, prop.clockRate * 1e-6);
-	printf("# a 'mix' line counts every instruction of its text; held clock = s_memtime ticks / s_memrealtime (100 MHz) at W=4\n");
-	printf("%-18s %7s %7s %7s %7s %7s %9s  %s\n", "instruction", "W=1", "W=2", "W=3", "W=4", "W=8", "clock GHz", "n/text");
-	const int wlist[5] = {1, 2, 3, 4, 8};
+	const int rounds = 6;
+	std::vector<long long> h((size_t)cus * 8 * rounds * 4);
+	hipEvent_t e0, e1;
+	hipEventCreate(&e0), hipEventCreate(&e1);
+	// W resident waves per SIMD are ENFORCED through LDS: a block is 256 threads (one wave per SIMD) and asks for so much dynamic LDS
+	// that exactly W blocks fit the CU's 160 KiB; the grid holds `rounds` times what the chip can hold, so that in the steady state every
+	// CU has W blocks whatever the dispatcher's placement.  Two clocks: per-block s_memtime (median; shader cycles one wave needs with
+	// W-1 partners on its SIMD) and HIP events around the whole launch (wall).
+	const int lds_kb[9] = {0, 81, 54, 41, 33, 27, 23, 21, 19};
+	printf("# %d CUs, nominal %.2f GHz.  cyc = shader cycles (s_memtime, median block) per wave-instruction per SIMD with W resident waves per SIMD (LDS-enforced);\n", cus, prop.clockRate * 1e-6);
+	printf("# ns = wall-clock nanoseconds per wave-instruction per SIMD from HIP events over a grid of %d x W blocks per CU; GHz = clock held at W=4\n", rounds);
+	printf("%-18s", "instruction");
+	for (int w = 1; w <= 8; ++w) printf("  cyc W=%d", w);
+	for (int w = 1; w <= 8; ++w) printf("   ns W=%d", w);
+	printf("    GHz  n  CUs-used\n");
 	for (const Op &op : ops) {
 		if (filter && !strstr(op.name, filter)) continue;
 		int ninst = 1;
 		for (const char *p = op.text; *p; ++p) ninst += *p == '\n';
-		double r[5], ghz = 0;
-		for (int m = 0; m < 5; ++m) {
-			const int wps = wlist[m];
-			// wps waves per SIMD: blocks of 256 threads (one wave per SIMD each), wps blocks per CU
-			const int threads = wps == 8 ? 512 : 256, blocks = wps == 8 ? cus * 4 : cus * wps;
-			hipLaunchKernelGGL(op.fn, dim3(blocks), dim3(threads), 0, 0, out, cyc);  // warm
-			hipLaunchKernelGGL(op.fn, dim3(blocks), dim3(threads), 0, 0, out, cyc);
-			hipDeviceSynchronize();
-			hipMemcpy(h.data(), cyc, sizeof(long long) * 2 * blocks, hipMemcpyDeviceToHost);
+		double r[9], ns[9], ghz = 0;
+		int cu_used = 0;
+		for (int wps = 1; wps <= 8; ++wps) {
+			const int blocks = cus * wps * rounds;
+			const size_t lds = (size_t)lds_kb[wps] * 1024;
+			hipFuncSetAttribute((const void *)op.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+			hipLaunchKernelGGL(op.fn, dim3(blocks), dim3(256), lds, 0, out, cyc);  // warm
+			hipEventRecord(e0, 0);
+			hipLaunchKernelGGL(op.fn, dim3(blocks), dim3(256), lds, 0, out, cyc);
+			hipEventRecord(e1, 0);
+			hipEventSynchronize(e1);
+			float ms = 0;
+			hipEventElapsedTime(&ms, e0, e1);
+			hipMemcpy(h.data(), cyc, sizeof(long long) * 4 * blocks, hipMemcpyDeviceToHost);
 			std::vector<double> per(blocks);
 			double rt = 0, st = 0;
-			for (int b = 0; b < blocks; ++b) per[b] = (double)h[2 * b], st += (double)h[2 * b], rt += (double)h[2 * b + 1];
+			std::vector<int> seen(256 * 8, 0);
+			for (int b = 0; b < blocks; ++b) {
+				per[b] = (double)h[4 * b], st += (double)h[4 * b], rt += (double)h[4 * b + 1];
+				seen[(hwid_cu((unsigned)h[4 * b + 2]) + 256 * (int)(h[4 * b + 3] & 7)) % (256 * 8)] = 1;
+			}
 			std::sort(per.begin(), per.end());
-			const double med = per[blocks / 2];
-			r[m] = med / ((double)wps * ITERS * UNROLL * ninst);
-			if (wps == 4) ghz = st / rt * 0.1;
+			r[wps] = per[blocks / 2] / ((double)wps * ITERS * UNROLL * ninst);
+			ns[wps] = (double)ms * 1e6 / ((double)rounds * wps * ITERS * UNROLL * ninst);
+			if (wps == 4) {
+				ghz = st / rt * 0.1;
+				for (int v : seen) cu_used += v;
+			}
 		}
-		printf("%-18s %7.2f %7.2f %7.2f %7.2f %7.2f %9.2f  %d\n", op.name, r[0], r[1], r[2], r[3], r[4], ghz, ninst);
+		printf("%-18s", op.name);
+		for (int w = 1; w <= 8; ++w) printf(" %8.2f", r[w]);
+		for (int w = 1; w <= 8; ++w) printf(" %8.2f", ns[w]);
+		printf(" %6.2f %2d %4d\n", ghz, ninst, cu_used);
 		fflush(stdout);
 	}
 	return 0;
