@@ -16,8 +16,8 @@
 // other side (a cell inside the band always has an in-band diagonal predecessor), so any sentinel below all finite
 // scores reproduces it; the dispatcher sends tasks whose scores could reach -12000 to the int32 wave kernel.
 // Direction state: the reference keeps one byte per cell (ksw.c:547-561: 2 bits "where H came from", 2 bits "E continues",
-// 2 bits "F continues", of which 4 bits carry information).  Here a cell costs 4 bits -- d | e_continues<<2 |
-// f_continues<<3 -- eight cells (one 8-slot block) per dword, and ONLY the blocks a wave computes are written, to a
+// 2 bits "F continues", of which 4 bits carry information).  Here a cell costs 4 bits -- the sign bits of the four
+// differences the reference compares (see the fill) -- eight cells (one 8-slot block) per dword, and ONLY the blocks a wave computes are written, to a
 // per-wave HBM slab laid out [block][row][lane]: the fill's stores are one coalesced 256-byte line per block and row,
 // and the traceback (ksw.c:566-581: the reference's loop, one path per lane) walks up a block's rows, so the lanes of a
 // wave -- sorted by band width, hence with their paths in the same block -- share the lines they fetch.
@@ -33,14 +33,54 @@
 namespace bmh {
 
 constexpr int kNeg16 = -16384;
+constexpr int kTbRows = 16;     // rows of a path's block fetched together by the traceback (LDS strip of kTbRows x 64 dwords = 4 KB)
+constexpr int kStreamRows = 64; // rows of the {target base, incoming query base} stream staged in LDS at a time
 
 __device__ __forceinline__ int sel3(int mask, int a, int b) { return __builtin_amdgcn_bitop3_b32(mask, a, b, 0xca); }
 
+// ---- the cell in 16-bit arithmetic.  What an instruction costs on gfx950 depends on its class (profiles/r03_valu_issue_classes.md,
+// tools/microbench/valu_mix.hip): the 16-bit VOP2 forms (v_add/sub/max_i16 ...), v_lshrrev_b32 and v_bitop3_b32 issue every 2 cycles
+// per SIMD once 4 waves are resident, while v_max_i32, v_cmp, v_cndmask, every SDWA/DPP form and every other VOP3 issue every 4.
+// hipcc picks the 32-bit forms for this code, so the cell is spelled out.  Operands are 16-bit two's-complement values in the LOW
+// half of a VGPR; the 16-bit instructions ignore the high half of their inputs and zero it in their result.
+#define BMH_OP16(name, text)                                                                                            \
+	__device__ __forceinline__ int name(int a, int b)                                                                   \
+	{                                                                                                                   \
+		int d;                                                                                                          \
+		asm(text " %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));                                                             \
+		return d;                                                                                                       \
+	}
+BMH_OP16(add16, "v_add_u16")   // a + b
+BMH_OP16(sub16, "v_sub_u16")   // a - b: bit 15 = [a < b] while |a - b| < 32768
+BMH_OP16(max16, "v_max_i16")   // signed
+#undef BMH_OP16
+__device__ __forceinline__ int subk16(int a, int k) // a - k, k wave-uniform (SGPR or inline constant as src0 of v_subrev)
+{
+	int d;
+	asm("v_subrev_u16 %0, %1, %2" : "=v"(d) : "s"(k), "v"(a));
+	return d;
+}
+// H(i-1,j-1) (low half of r) + the score byte B of sc4, sign-extended: low half of the result = M(i,j)
+template <int B> __device__ __forceinline__ int add_score(int sc4, int r)
+{
+	int d;
+	if constexpr (B == 0) asm("v_add_u32_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:WORD_0" : "=v"(d) : "v"(sc4), "v"(r));
+	if constexpr (B == 1) asm("v_add_u32_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:WORD_0" : "=v"(d) : "v"(sc4), "v"(r));
+	if constexpr (B == 2) asm("v_add_u32_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:WORD_0" : "=v"(d) : "v"(sc4), "v"(r));
+	if constexpr (B == 3) asm("v_add_u32_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:WORD_0" : "=v"(d) : "v"(sc4), "v"(r));
+	return d;
+}
+// high half of r = max(a, b) (signed 16-bit), low half kept: E(i+1,j) goes in beside the H(i,j) already in r
+__device__ __forceinline__ void max16_into_hi(int &r, int a, int b)
+{
+	asm("v_max_i16_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0" : "+v"(r) : "v"(a), "v"(b));
+}
+
 #ifndef BMH_GL_WAVES64
-#define BMH_GL_WAVES64 2 /* measured: (2,1) 3.08 ms, (3,1) 3.21 ms, (3,2) 3.67 ms per 250k tasks */
+#define BMH_GL_WAVES64 3 /* round 3 (16-bit cell): 3 waves per SIMD hold the row loop without scratch traffic; 4 do not (100+ spills) */
 #endif
 #ifndef BMH_GL_WAVES128
-#define BMH_GL_WAVES128 1
+#define BMH_GL_WAVES128 2
 #endif
 #ifndef BMH_GL_WAVES96
 #define BMH_GL_WAVES96 2
@@ -54,6 +94,7 @@ __global__ __launch_bounds__(64, (C <= 64 ? BMH_GL_WAVES64 : C <= 96 ? BMH_GL_WA
 {
 	constexpr int NW = C / 32, NQ = C / 4, NB = C / 8;
 	__shared__ uint2 srow[8];
+	extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[]; // max(C, kStreamRows) x 64 bytes: the window staging, then the per-row stream
 	const int lane = threadIdx.x;
 	const int oe_del = P.o_del + P.e_del, oe_ins = P.o_ins + P.e_ins;
 	const int e_del = P.e_del, e_ins = P.e_ins;
@@ -63,7 +104,8 @@ __global__ __launch_bounds__(64, (C <= 64 ? BMH_GL_WAVES64 : C <= 96 ? BMH_GL_WA
 		srow[lane] = make_uint2(lo, (uint32_t)(uint8_t)mat_at(P, lane * 5 + 4));
 	}
 	const long long cnt = count ? (long long)*count : n;
-	uint32_t *__restrict__ zw = zslab + (size_t)blockIdx.x * (size_t)rows_cap * (size_t)(NB * 64) + lane;
+	// this wave's direction slab: a wave-uniform base (SGPRs); a store then needs only `lane` as its 32-bit vector offset
+	uint32_t *__restrict__ zbase = zslab + (size_t)blockIdx.x * (size_t)rows_cap * (size_t)(NB * 64);
 
 	for (long long base = (long long)blockIdx.x * 64; base < cnt; base += (long long)gridDim.x * 64) {
 		const bool valid = base + lane < cnt;
@@ -71,12 +113,10 @@ __global__ __launch_bounds__(64, (C <= 64 ? BMH_GL_WAVES64 : C <= 96 ? BMH_GL_WA
 		const uint32_t idx = order ? order[pos] : (uint32_t)pos;
 		const uint4 *tp = (const uint4 *)(tasks + idx);
 		const uint4 ta = tp[0], tb = tp[1];
-		const uint64_t q_off = (uint64_t)ta.y << 32 | ta.x, t_off = (uint64_t)ta.w << 32 | ta.z;
+		const uint64_t q_off = (uint64_t)ta.y << 32 | ta.x;
 		const int qlen = (int)(tb.x & 0xffff), tlen = (int)(tb.x >> 16);
 		const int w = (int)tb.y;
-		const uint32_t cigar_off = tb.z;
-		const int cigar_cap = (int)tb.w;
-		const bool want = cigar_cap > 0;
+		const bool want = (int)tb.w > 0;
 		const bool bad = w < 0 || 2 * w + 2 > C || tlen > rows_cap;
 		if (valid && bad) {
 			out[idx].score = INT32_MIN, out[idx].n_cigar = 0;
@@ -92,7 +132,16 @@ __global__ __launch_bounds__(64, (C <= 64 ? BMH_GL_WAVES64 : C <= 96 ? BMH_GL_WA
 			const int hd = j < 0 ? kNeg16 : (j == 0 ? 0 : (j <= w && j <= qlen ? -(P.o_ins + e_ins * j) : kNeg16));
 			R[s] = (int)((uint32_t)kNeg16 << 16 | ((uint32_t)hd & 0xffffu)); // {H(-1,j-1) as eh[j].h, E = -inf}
 		}
-#pragma unroll
+		// ---- the sequences go through LDS.  (1) The query window: unrolled, its C byte loads are all in flight at once and their 64-bit
+		// addresses and destinations set the kernel's register count (226 for C = 64); fetched in a rolled loop into LDS and read back
+		// into QW[], the row loop fits 3 waves per SIMD.  (2) The per-row stream: row i consumes target base t[i] and the query base that
+		// enters the window's top slot, q[i+C-w]; loaded from global memory inside the row loop they cost an `s_waitcnt vmcnt(0)` per row
+		// (loads under an exec mask cannot be counted, and the counter they share with the direction-word stores runs in order: 40 % of
+		// the waves' lifetime was spent waiting).  Both are staged in LDS, one byte per row (two nibbles) at [row][lane], kStreamRows rows
+		// at a time: the row loop waits for memory once per kStreamRows rows.  The window staging area is reused for the stream.
+		uint8_t *strm = dyn_lds;
+		uint32_t *qstage = (uint32_t *)dyn_lds;
+#pragma unroll 2
 		for (int v = 0; v < NQ; ++v) {
 			int sv = 0;
 #pragma unroll
@@ -102,24 +151,47 @@ __global__ __launch_bounds__(64, (C <= 64 ? BMH_GL_WAVES64 : C <= 96 ? BMH_GL_WA
 				if (live && j >= 0 && j < qlen) qb = pool[q_off + (uint64_t)j];
 				sv |= qb << (8 * b);
 			}
-			QW[v] = sv;
+			qstage[v * 64 + lane] = (uint32_t)sv;
 		}
-		int tnext = 0, qnext = 4;
-		if (live && tlen > 0) tnext = pool[t_off];
-		{
-			const int j = 1 - w + C - 1; // the byte that enters slot C-1 at row 1
-			if (live && j >= 0 && j < qlen) qnext = pool[q_off + (uint64_t)j];
-		}
+#pragma unroll
+		for (int v = 0; v < NQ; ++v) QW[v] = (int)qstage[v * 64 + lane];
+		// the stream holds kStreamRows rows at a time and is refilled by the row loop every kStreamRows rows (one wait per chunk)
+		const int qsh = C - w; // row i takes q[i + qsh] into the top slot of the window of row i+1
+		auto fill_stream = [&](int r0) {
+			// the sequence offsets are read again from the task record here (once per kStreamRows rows) instead of living in four
+			// VGPRs through the row loop: a spilled register costs a scratch reload per row, and that reload's s_waitcnt vmcnt(0)
+			// also waits for every direction-word store in flight
+			const uint4 tq = *(const uint4 *)(tasks + idx);
+			const uint64_t q_off = (uint64_t)tq.y << 32 | tq.x, t_off = (uint64_t)tq.w << 32 | tq.z;
+#pragma unroll 2
+			for (int r4 = 0; r4 < kStreamRows; r4 += 4) { // four rows per trip: one (unaligned) dword of each sequence where it fits
+				const int r = r0 + r4;
+				uint32_t t4 = 0, q4 = 0x04040404u;
+				if (live && r + 4 <= tlen) __builtin_memcpy(&t4, pool + t_off + (uint64_t)r, 4);
+				else if (live) {
+#pragma unroll
+					for (int k = 0; k < 4; ++k)
+						if (r + k < tlen) t4 |= (uint32_t)pool[t_off + (uint64_t)(r + k)] << (8 * k);
+				}
+				if (live && r + qsh + 4 <= qlen) __builtin_memcpy(&q4, pool + q_off + (uint64_t)(r + qsh), 4);
+				else if (live) {
+#pragma unroll
+					for (int k = 0; k < 4; ++k)
+						if (r + qsh + k < qlen) q4 = (q4 & ~(0xffu << (8 * k))) | (uint32_t)pool[q_off + (uint64_t)(r + qsh + k)] << (8 * k);
+				}
+				const uint32_t m4 = (t4 & 0x0f0f0f0fu) | (q4 & 0x0f0f0f0fu) << 4;
+#pragma unroll
+				for (int k = 0; k < 4; ++k) strm[(r4 + k) * 64 + lane] = (uint8_t)(m4 >> (8 * k));
+			}
+		};
 		int i = 0, score = kNeg16;
 		for (; __builtin_amdgcn_ballot_w64(live && i < tlen) != 0; ++i) { // ksw.c:524-564; i is wave-uniform
 			const bool rowon = live && i < tlen;
-			const int tcur = tnext, qin = qnext;
-			tnext = 0, qnext = 4;
-			if (live && i + 1 < tlen) tnext = pool[t_off + (uint64_t)(i + 1)];
-			{
-				const int j = i + 2 - w + C - 1;
-				if (live && i + 2 < tlen && j >= 0 && j < qlen) qnext = pool[q_off + (uint64_t)j];
-			}
+			if ((i & (kStreamRows - 1)) == 0) fill_stream(i); // wave-uniform: rows [i, i + kStreamRows) of the {t, q} stream
+			int lane_now; // (recomputed each row on purpose: kept live across the row it would be spilled, see fill_stream)
+			asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_now));
+			const int sbyte = strm[(i & (kStreamRows - 1)) * 64 + lane_now];
+			const int tcur = sbyte & 15, qin = sbyte >> 4;
 			const uint2 row = srow[min(tcur, 4)];
 			const int slo = rowon ? max(0, w - i) : C + 1;
 			const int shi = rowon ? min(2 * w + 1, qlen - i + w) : C + 1;
@@ -131,55 +203,86 @@ __global__ __launch_bounds__(64, (C <= 64 ? BMH_GL_WAVES64 : C <= 96 ? BMH_GL_WA
 			}
 			const int fill = i < w ? -(P.o_del + e_del * (i + 1)) : kNeg16; // ksw.c:530: first-column value while beg == 0
 			int f = kNeg16;
-			uint32_t *zrow = zw + (size_t)i * 64;
 #pragma unroll
 			for (int b = 0; b < NB; ++b) {
 				// needed iff the block meets [slo-1, shi): slot slo-1 is the virtual column -1 that must receive `fill`
 				if (__builtin_amdgcn_ballot_w64(slo <= 8 * b + 8 && shi > 8 * b) == 0) continue;
-				uint32_t dz = 0;
 				// FAST: a block whose eight slots lie inside the band of EVERY lane still running needs no activity masks (no
 				// select on F, E and H, no fill); lanes past their last row compute garbage into their own registers
 				const bool masked = !FAST || __builtin_amdgcn_ballot_w64(rowon && !(slo <= 8 * b && shi >= 8 * b + 8)) != 0;
+				// Direction state, 4 bits per cell, as the SIGN BITS of four differences (ksw.c:547-561):
+				//   b1 = [m < e]  b2 = [max(m,e) < f]            -> d = b2 ? 2 : b1
+				//   b3 = [e - e_del > m - oe_del] (E continues)    b4 = [f - e_ins > m - oe_ins] (F continues)
+				// b1,b2 of cell c end up in bits 2c+1, 2c of the block's dword, b3,b4 in bits 16+2c+1, 16+2c: two 16-bit
+				// shift registers (dz12, dz34) take two bits per cell at their top and move down two places per cell.
+				int dz12 = 0, dz34 = 0;
 				auto cells = [&](auto MASKED) {
 #pragma unroll
-					for (int c = 0; c < 8; ++c) {
-						const int s = 8 * b + c;
-						const unsigned sel = __builtin_amdgcn_perm((unsigned)QW[s / 4], row.y, 0x0c0c0c04u + (unsigned)(s % 4));
-						const int sc = (int)(int8_t)__builtin_amdgcn_perm(row.y, row.x, sel);
-						const int m = (int)(int16_t)(R[s] & 0xffff) + sc; // M(i,j) = H(i-1,j-1) + S, ksw.c:546
-						const int e = R[s + 1] >> 16;                      // E(i,j)
-						int d = m >= e ? 0 : 1;                            // ksw.c:547-550
-						int h = max(m, e);
-						d = h >= f ? d : 2;
-						h = max(h, f);
-						const int t1 = m - oe_del, e2 = e - e_del;         // ksw.c:552-556
-						d |= e2 > t1 ? 4 : 0;
-						const int en = max(e2, t1);
-						const int t2 = m - oe_ins, f2 = f - e_ins;         // ksw.c:557-560
-						d |= f2 > t2 ? 8 : 0;
-						// register s <- {H(i,j) for the next row's diagonal, E(i+1,j) for the next row's slot s-1}
-						if constexpr (decltype(MASKED)::value) {
-							const int actv = (am[s / 32] << (31 - s % 32)) >> 31;
-							f = sel3(actv, max(f2, t2), kNeg16);
-							R[s] = (int)__builtin_amdgcn_perm((unsigned)sel3(actv, en, kNeg16), (unsigned)sel3(actv, h, fill), 0x05040100u);
-						} else {
-							f = max(f2, t2);
-							R[s] = (int)__builtin_amdgcn_perm((unsigned)en, (unsigned)h, 0x05040100u);
+					for (int q4 = 0; q4 < 2; ++q4) {
+						// the four substitution scores of slots 8b+4q4 .. +3 with one v_perm: the query codes are the selectors
+						const int sc4 = (int)__builtin_amdgcn_perm(row.y, row.x, (unsigned)QW[2 * b + q4]);
+#pragma unroll
+						for (int c4 = 0; c4 < 4; ++c4) {
+							const int s = 8 * b + 4 * q4 + c4;
+							const int m = c4 == 0 ? add_score<0>(sc4, R[s]) : c4 == 1 ? add_score<1>(sc4, R[s]) : c4 == 2 ? add_score<2>(sc4, R[s]) : add_score<3>(sc4, R[s]); // ksw.c:546
+							const int e = (int)((unsigned)R[s + 1] >> 16);  // E(i,j)
+							const int h1 = max16(m, e);                     // ksw.c:547-550
+							const int h = max16(h1, f);
+							const int x1 = sub16(m, e), x2 = sub16(h1, f);
+							const int t1 = subk16(m, oe_del), e2 = subk16(e, e_del); // ksw.c:552-556
+							const int x3 = sub16(t1, e2);
+							const int t2 = oe_ins == oe_del ? t1 : subk16(m, oe_ins), f2 = subk16(f, e_ins); // ksw.c:557-560
+							const int x4 = sub16(t2, f2);
+							const int z12 = __builtin_amdgcn_bitop3_b32(0x8000, x1, (int)((unsigned)x2 >> 1), 0xca);
+							const int z34 = __builtin_amdgcn_bitop3_b32(0x8000, x3, (int)((unsigned)x4 >> 1), 0xca);
+							dz12 = __builtin_amdgcn_bitop3_b32((int)((unsigned)dz12 >> 2), z12, 0xc000, 0xf8); // a | (b & c)
+							dz34 = __builtin_amdgcn_bitop3_b32((int)((unsigned)dz34 >> 2), z34, 0xc000, 0xf8);
+							// register s <- {H(i,j) for the next row's diagonal, E(i+1,j) for the next row's slot s-1}
+							if constexpr (decltype(MASKED)::value) {
+								const int actv = (am[s / 32] << (31 - s % 32)) >> 31;
+								f = sel3(actv, max16(f2, t2), kNeg16);
+								R[s] = (int)__builtin_amdgcn_perm((unsigned)sel3(actv, max16(e2, t1), kNeg16), (unsigned)sel3(actv, h, fill), 0x05040100u);
+							} else {
+								f = max16(f2, t2);
+								int r = h;
+								max16_into_hi(r, e2, t1);
+								R[s] = r;
+							}
+#ifdef BMH_GL_SCHED_CELL
+							__builtin_amdgcn_sched_barrier(0);
+#endif
 						}
-						dz |= (uint32_t)d << (4 * c);
+#ifdef BMH_GL_SCHED_Q4
+						__builtin_amdgcn_sched_barrier(0);
+#endif
 					}
 				};
 				if (masked) cells(std::true_type{});
 				else if constexpr (FAST) cells(std::false_type{});
-				if (want) zrow[(size_t)b * (size_t)rows_cap * 64] = dz; // ksw.c:561, eight cells at once
+				const uint32_t dz = (uint32_t)dz12 | (uint32_t)dz34 << 16;
+				if (want) { // ksw.c:561, eight cells at once: wave-uniform line address in SGPRs + the lane's byte offset
+					const uint32_t *line = zbase + ((size_t)b * (size_t)rows_cap + (size_t)i) * 64;
+					asm volatile("global_store_dword %0, %1, %2" : : "v"(lane * 4), "v"(dz), "s"(line) : "memory");
+				}
 			}
 			// score = eh[qlen].h after the LAST row of a lane = H(tlen-1, qlen-1), ksw.c:565: slot qlen-tlen+w of that row.
 			// Picked up right here because the registers of a finished lane are refilled by the rows other lanes still run.
 			if (__builtin_amdgcn_ballot_w64(live && i == tlen - 1)) {
+				// register number ss picked by a binary tree of selects on the bits of ss (C-1 selects and log2 C compares; a compare per
+				// register, hoisted out of the row loop by the compiler, used to cost 2 SGPRs per slot)
 				const int ss = qlen - tlen + w;
+				constexpr int CP = C <= 64 ? 64 : 128;
+				int T[CP / 2];
 #pragma unroll
-				for (int s = 0; s < C; ++s)
-					if (live && i == tlen - 1 && s == ss) score = (int)(int16_t)(R[s] & 0xffff);
+				for (int k = 0; k < CP / 2; ++k) {
+					const int a0 = 2 * k < C ? R[2 * k] : 0, a1 = 2 * k + 1 < C ? R[2 * k + 1] : 0;
+					T[k] = (ss & 1) ? a1 : a0;
+				}
+#pragma unroll
+				for (int bit = 1, len = CP / 4; len >= 1; ++bit, len >>= 1)
+#pragma unroll
+					for (int k = 0; k < len; ++k) T[k] = (ss >> bit & 1) ? T[2 * k + 1] : T[2 * k];
+				if (live && i == tlen - 1 && ss >= 0 && ss < C) score = (int)(int16_t)(T[0] & 0xffff);
 			}
 			// slide the query window by one base (row i+1 looks at q[i+1-w+s])
 #pragma unroll
@@ -191,17 +294,40 @@ __global__ __launch_bounds__(64, (C <= 64 ? BMH_GL_WAVES64 : C <= 96 ? BMH_GL_WA
 		if (score <= kNeg16 / 2) score = -0x40000000; // the reference's MINUS_INF (out-of-domain input only)
 
 		// ---- traceback, ksw.c:566-581, one path per lane
+		const uint2 tc = *(const uint2 *)((const uint8_t *)(tasks + idx) + 24); // {cigar_off, cigar_cap}, re-read (see fill_stream)
+		const uint32_t cigar_off = tc.x;
+		const int cigar_cap = (int)tc.y;
 		int n_cigar = 0;
 		if (__builtin_amdgcn_ballot_w64(live && want)) {
 			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); // direction words of this wave are in flight
 			uint32_t *cg = cigar_pool + cigar_off;
 			int ti = tlen - 1, tk = min(qlen, tlen - 1 + w + 1) - 1, which = 0, last_op = 0, last_len = 0, nw = 0;
 			bool on = live && want;
+			// A step needs one direction dword; read from the slab where the fill left it, every step is a dependent HBM/L2 round trip
+			// (a third of the waves' lifetime, profiles/r03_global_lane.md).  A path moves up one row per step (two steps at an insertion) and
+			// rarely leaves its 8-slot block, so the dwords of its block for the next kTbRows rows are fetched together -- kTbRows loads in
+			// flight per lane -- into an LDS strip [k][lane], refilled for ALL lanes of the wave whenever one of them runs out (the lanes'
+			// paths advance about a row per step, so they run out together).
+			uint32_t *strip = (uint32_t *)dyn_lds;
+			int cblk = -1, ctop = -1; // block and top row of this lane's strip: rows (ctop - kTbRows, ctop]
 			while (__builtin_amdgcn_ballot_w64(on && ti >= 0 && tk >= 0)) {
-				if (on && ti >= 0 && tk >= 0) {
-					const int s = min(max(tk - (ti - w), 0), C - 1);
-					const uint32_t nib = zw[((size_t)(s >> 3) * (size_t)rows_cap + (size_t)ti) * 64] >> (4 * (s & 7));
-					which = which == 0 ? (int)(nib & 3) : which == 1 ? (int)(nib >> 2 & 1) : (int)(nib >> 2 & 2);
+				const bool act = on && ti >= 0 && tk >= 0;
+				const int s = min(max(tk - (ti - w), 0), C - 1);
+				if (__builtin_amdgcn_ballot_w64(act && ((s >> 3) != cblk || ti > ctop || ti <= ctop - kTbRows))) {
+					if (act) {
+						cblk = s >> 3, ctop = ti;
+						const uint32_t *src = zbase + ((size_t)cblk * (size_t)rows_cap) * 64 + lane;
+						uint32_t v[kTbRows];
+#pragma unroll
+						for (int k = 0; k < kTbRows; ++k) v[k] = ti - k >= 0 ? src[(size_t)(ti - k) * 64] : 0u;
+#pragma unroll
+						for (int k = 0; k < kTbRows; ++k) strip[k * 64 + lane] = v[k];
+					}
+				}
+				if (act) {
+					const uint32_t dzw = strip[(ctop - ti) * 64 + lane] >> (2 * (s & 7));
+					// bits 1,0 = [m < e], [max(m,e) < f]; bits 17,16 = E continues, F continues (see the fill)
+					which = which == 0 ? ((dzw & 1) ? 2 : (int)(dzw >> 1 & 1)) : which == 1 ? (int)(dzw >> 17 & 1) : (int)(dzw >> 15 & 2);
 					const int op = which == 0 ? 0 : (which == 1 ? 2 : 1);
 					if (last_len > 0 && op == last_op) ++last_len; // ksw.c:489-499
 					else {
@@ -266,13 +392,14 @@ int launch_global_lane(bmh_ctx *ctx, int c, const uint8_t *d_pool, const bmh_glb
 	int rc = ensure(ctx, ctx->d_zslab, slab);
 	if (rc) return rc;
 	const bool fast = ctx->glb_fast != 0; // (A/B knob BMH_GL_FAST: 0 = masked body only)
+	const size_t lds = (size_t)std::max(c, kStreamRows) * 64; // window staging (C/4 dwords per lane), then one byte per staged row and lane
 #define BMH_LAUNCH_GL(CC)                                                                                                      \
 	do {                                                                                                                       \
 		if (fast)                                                                                                              \
-			hipLaunchKernelGGL((global_lane_kernel<CC, true>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_pool, d_tasks, d_order, \
+			hipLaunchKernelGGL((global_lane_kernel<CC, true>), dim3((unsigned)grid), dim3(64), lds, ctx->stream, d_pool, d_tasks, d_order, \
 			                   d_count, (long long)n, d_res, d_cigar, ctx->dev, (uint32_t *)ctx->d_zslab.p, rows_cap, ctx->d_err);     \
 		else                                                                                                                   \
-			hipLaunchKernelGGL((global_lane_kernel<CC, false>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_pool, d_tasks, d_order, \
+			hipLaunchKernelGGL((global_lane_kernel<CC, false>), dim3((unsigned)grid), dim3(64), lds, ctx->stream, d_pool, d_tasks, d_order, \
 			                   d_count, (long long)n, d_res, d_cigar, ctx->dev, (uint32_t *)ctx->d_zslab.p, rows_cap, ctx->d_err);    \
 	} while (0)
 	if (c == 64) BMH_LAUNCH_GL(64);

@@ -68,7 +68,7 @@ def assemble(hip, extra):
     out = tempfile.NamedTemporaryFile(suffix=".s", delete=False).name
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-S", "--cuda-device-only", "-I", os.path.join(root, "include"),
-           "-o", out, hip] + extra
+           "-mllvm", "-pragma-unroll-threshold=200000", "-o", out, hip] + extra
     subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
     return out
 
