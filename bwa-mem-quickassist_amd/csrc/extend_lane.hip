@@ -22,23 +22,20 @@
 //     finishes (m==0, z-drop, last row) writes its result and idles until the wave is done.  The dispatcher
 //     hands this kernel tasks SORTED by expected row count, so lanes of a wave finish together.
 #include <algorithm>
+#include <type_traits>
 
 #include "bmh_ctx.h"
 #include "bmh_device.h"
 
 namespace bmh {
 
-#ifndef BMH_LANE_HOIST_LIMIT
-#define BMH_LANE_HOIST_LIMIT 128
+#ifndef BMH_LANE_INTERIOR
+#define BMH_LANE_INTERIOR 0 /* measured on the 20 M-read step: 81.7 ms with the unmasked body for interior blocks (27 spilled VGPRs at C = 64), 82.3 ms without */
 #endif
-constexpr int kLaneHoistLimit = BMH_LANE_HOIST_LIMIT;
-#ifndef BMH_LANE_FAST_BLOCKS
-#define BMH_LANE_FAST_BLOCKS 0 /* measured: 5.34 ms vs 4.78 ms per 1M-read batch with it on (register pressure, code size) */
-#endif
-constexpr bool kLaneFastBlocks = BMH_LANE_FAST_BLOCKS; // unpredicated body for blocks interior to every live lane's interval
+constexpr bool kLaneInterior = BMH_LANE_INTERIOR; // unmasked body for blocks interior to every live lane's interval
 // waves per SIMD the register allocator must leave room for (2nd launch-bounds argument)
 #ifndef BMH_LANE_WAVES
-#define BMH_LANE_WAVES(C) ((C) <= 32 ? 4 : (C) <= 64 ? 3 : 2)
+#define BMH_LANE_WAVES(C) ((C) <= 32 ? 5 : (C) <= 64 ? 4 : 2)
 #endif
 
 // per-bit select: mask ? a : b  (one v_bitop3_b32 on gfx950)
@@ -58,6 +55,13 @@ __global__ __launch_bounds__(64, BMH_LANE_WAVES(C)) void extend_lane_kernel(cons
 	constexpr int NW = C / 32, NQ = C / 4, NB = C / 8;
 	constexpr int INF = 0x7fff;
 	__shared__ uint2 srow[8]; // srow[t] = the 5 signed score bytes mat[t*5 .. t*5+4]
+	// A task's sequences pass through LDS.  The query selectors are fetched in a ROLLED loop into `stage` and read back into QS[]:
+	// unrolled, the C byte loads are all in flight at once and their 64-bit addresses and destinations (3 VGPRs each) set the kernel's
+	// register count.  The target is then streamed through the same area kStreamRows rows at a time, one byte per row at [row][lane]:
+	// loaded inside the row loop (under an exec mask, so that the compiler cannot count it) every row paid an `s_waitcnt vmcnt(0)` right
+	// behind the load -- a full memory round trip per DP row.
+	constexpr int kStreamRows = 64;
+	__shared__ uint32_t stage[(C > kStreamRows ? C : kStreamRows) * 16]; // C/4 dwords x 64 lanes, or kStreamRows x 64 bytes
 #ifdef BMH_LANE_LDS_SEL
 	__shared__ uint8_t qsel[C * 64]; // query code of column p of lane l at [p*64+l]: one conflict-free ds_read_u8 per cell
 #endif
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(64, BMH_LANE_WAVES(C)) void extend_lane_kernel(cons
 	}
 #else
 	int QS[NQ];
-#pragma unroll
+#pragma unroll 2
 	for (int v = 0; v < NQ; ++v) {
 		int s = 0;
 #pragma unroll
@@ -117,8 +121,10 @@ __global__ __launch_bounds__(64, BMH_LANE_WAVES(C)) void extend_lane_kernel(cons
 			if (valid && !bad && j >= 0) qb = seq_base(pool, q_off, j, qrev);
 			s |= qb << (8 * b);
 		}
-		QS[v] = s;
+		stage[v * 64 + lane] = (uint32_t)s;
 	}
+#pragma unroll
+	for (int v = 0; v < NQ; ++v) QS[v] = (int)stage[v * 64 + lane];
 #endif
 #pragma unroll
 	for (int p = 0; p < C; ++p) {
@@ -134,12 +140,18 @@ __global__ __launch_bounds__(64, BMH_LANE_WAVES(C)) void extend_lane_kernel(cons
 		int *p = (int *)(out + idx);
 		p[0] = h0, p[1] = 0, p[2] = 0, p[3] = 0, p[4] = -1, p[5] = 0;
 	}
-	int tnext = alive ? tgt_base(pool, P, t_off, 0, trev, tpac) : 0;
+	uint8_t *strm = (uint8_t *)stage;
 
 	for (int i = 0; __builtin_amdgcn_ballot_w64(alive) != 0; ++i) { // i is wave-uniform: all tasks started together
-		const int tcur = tnext;
-		tnext = 0;
-		if (alive && i + 1 < tlen) tnext = tgt_base(pool, P, t_off, i + 1, trev, tpac); // consumed one row later
+		if ((i & (kStreamRows - 1)) == 0) { // wave-uniform: target rows [i, i + kStreamRows) of every lane still running
+#pragma unroll 4
+			for (int r = 0; r < kStreamRows; ++r) {
+				int tb = 0;
+				if (alive && i + r < tlen) tb = tgt_base(pool, P, t_off, i + r, trev, tpac);
+				strm[r * 64 + lane] = (uint8_t)tb;
+			}
+		}
+		const int tcur = strm[(i & (kStreamRows - 1)) * 64 + lane];
 		const uint2 row = srow[min(tcur, 4)];
 		begp = max(begp, i - w + off);     // ksw.c:418-420
 		endp = min(endp, i + w + 1 + off); // endp <= C covers the qlen clamp
@@ -160,58 +172,48 @@ __global__ __launch_bounds__(64, BMH_LANE_WAVES(C)) void extend_lane_kernel(cons
 		for (int b = 0; b < NB; ++b) {
 			// the block is needed by a lane iff [8b,8b+8) meets [beg,end]  (end itself receives eh[end])
 			if (__builtin_amdgcn_ballot_w64(lb < 8 * b + 8 && le >= 8 * b) == 0) continue;
-			// Interior block: every live lane has all 8 columns inside [beg,end) -> no predication needed (finished
-			// lanes may compute junk, their results are already written).  Edge blocks take the predicated body.
-			if (kLaneFastBlocks && __builtin_amdgcn_ballot_w64(alive && !(lb <= 8 * b && le >= 8 * b + 8)) == 0) {
+			// The cell in 16-bit instructions (bmh_device.h; issue classes: profiles/r03_valu_issue_classes.md).  Every quantity of the
+			// recurrence is >= 0 except M = H(i-1,j-1) + S, which only enters a signed maximum with E >= 0.
+			// An INTERIOR block -- all eight columns inside [beg,end) of every lane still running -- needs no activity masks: five of a
+			// cell's nineteen instructions (finished lanes compute junk there; their results are already written).
+			const bool edge = !kLaneInterior || __builtin_amdgcn_ballot_w64(alive && !(lb <= 8 * b && le >= 8 * b + 8)) != 0;
+			auto cells = [&](auto MASKED) {
 #pragma unroll
-				for (int c = 0; c < 8; ++c) {
-					const int p = 8 * b + c;
+				for (int q4 = 0; q4 < 2; ++q4) {
 #ifdef BMH_LANE_LDS_SEL
-					const unsigned sel = qsel[p * 64 + lane];
+					int sc4 = 0;
+#pragma unroll
+					for (int c4 = 0; c4 < 4; ++c4) sc4 |= (int)(__builtin_amdgcn_perm(row.y, row.x, (unsigned)qsel[(8 * b + 4 * q4 + c4) * 64 + lane]) & 0xffu) << (8 * c4);
 #else
-					const unsigned sel = __builtin_amdgcn_perm((unsigned)QS[p / 4], C >= kLaneHoistLimit ? row.y : 0u,
-					                                           0x0c0c0c04u + (unsigned)(p % 4));
+					// the four substitution scores of columns 8b+4q4 .. +3 with one v_perm: the query codes are the selectors
+					const int sc4 = (int)__builtin_amdgcn_perm(row.y, row.x, (unsigned)QS[2 * b + q4]);
 #endif
-					const int sc = (int)(int8_t)__builtin_amdgcn_perm(row.y, row.x, sel);
-					const int e = (int)((unsigned)HE[p] >> 16);
-					const int h = max(max((int)(HE[p] & 0xffff) + sc, e), f);    // ksw.c:430-432
-					const int hod = h - oe_del, hoi = SYM ? hod : h - oe_ins;
-					const int en = max(max(e - e_del, hod), 0);                  // ksw.c:436-439
-					f = max(max(f - e_ins, hoi), 0);                             // ksw.c:441-444
-					HE[p] = en << 16 | hprev;
-					kmax = max(kmax, h << 16 | p);
-					nz[p / 32] |= (int)(min((unsigned)h, 1u) << (p % 32));
-					hprev = h;
-					if (p == C - 1) hlast = h;
+#pragma unroll
+					for (int c4 = 0; c4 < 4; ++c4) {
+						const int p = 8 * b + 4 * q4 + c4;
+						const int m = c4 == 0 ? add_score<0>(sc4, HE[p]) : c4 == 1 ? add_score<1>(sc4, HE[p]) : c4 == 2 ? add_score<2>(sc4, HE[p]) : add_score<3>(sc4, HE[p]);
+						const int e = (int)((unsigned)HE[p] >> 16);
+						const int h = max16(max16(m, e), f);                             // ksw.c:430-432
+						const int t = subc16(h, oe_del);                                 // max(h - oe_del, 0)
+						int en = maxu16(subc16(e, e_del), t);                            // ksw.c:436-439
+						f = maxu16(subc16(f, e_ins), SYM ? t : subc16(h, oe_ins));       // ksw.c:441-444
+						int ha = h, hn = h;
+						if constexpr (decltype(MASKED)::value) {
+							const int actv = (am[p / 32] << (31 - p % 32)) >> 31;
+							en &= actv, f &= actv;
+							ha = bfi2(actv, h, -1);                                      // -1 outside the interval
+							hn = bfi2(actv, h, left);
+						}
+						HE[p] = en << 16 | hprev;                                        // eh[j] = {H(i,j-1), E(i+1,j)}, ksw.c:429,440
+						kmax = max(kmax, ha << 16 | p);                                  // row max, ties -> larger j (ksw.c:434)
+						nz[p / 32] |= nonzero16(h) << (p % 32);                         // only live columns are looked at later (& am)
+						hprev = hn;
+						if (p == C - 1) hlast = ha;
+					}
 				}
-				continue;
-			}
-#pragma unroll
-			for (int c = 0; c < 8; ++c) {
-				const int p = 8 * b + c;
-				const int actv = (am[p / 32] << (31 - p % 32)) >> 31;
-#ifdef BMH_LANE_LDS_SEL
-				const unsigned sel = qsel[p * 64 + lane];
-#else
-				// selector = query code of column p in byte 0.  The second operand is never selected; passing a
-				// row-variant value for C >= HOIST_LIMIT keeps hipcc from hoisting C selectors into C more VGPRs.
-				const unsigned sel = __builtin_amdgcn_perm((unsigned)QS[p / 4], C >= kLaneHoistLimit ? row.y : 0u,
-				                                           0x0c0c0c04u + (unsigned)(p % 4));
-#endif
-				const int sc = (int)(int8_t)__builtin_amdgcn_perm(row.y, row.x, sel);
-				const int e = (int)((unsigned)HE[p] >> 16);
-				const int hh = max((int)(HE[p] & 0xffff) + sc, e);          // ksw.c:430-431
-				const int h = max(hh, f);                                   // ksw.c:432
-				const int hod = h - oe_del, hoi = SYM ? hod : h - oe_ins;
-				const int en = max(max(e - e_del, hod), 0) & actv;          // ksw.c:436-439
-				f = max(max(f - e_ins, hoi), 0) & actv;                     // ksw.c:441-444
-				HE[p] = en << 16 | hprev;                                   // eh[j] = {H(i,j-1), E(i+1,j)}, ksw.c:429,440
-				const int ha = bfi2(actv, h, -1);                           // -1 outside the interval
-				kmax = max(kmax, ha << 16 | p);                             // row max, ties -> larger j (ksw.c:434)
-				nz[p / 32] |= (int)(min((unsigned)h, 1u) << (p % 32)); // only live columns are looked at later (& am)
-				hprev = bfi2(actv, h, left);
-				if (p == C - 1) hlast = ha;
-			}
+			};
+			if (edge) cells(std::true_type{});
+			else if constexpr (kLaneInterior) cells(std::false_type{});
 		}
 		// ---- row end, per lane
 		gk = max(gk, hlast << 16 | i); // column qlen-1 live in this row: ksw.c:447-450 (ties -> later row)

@@ -38,44 +38,6 @@ constexpr int kStreamRows = 64; // rows of the {target base, incoming query base
 
 __device__ __forceinline__ int sel3(int mask, int a, int b) { return __builtin_amdgcn_bitop3_b32(mask, a, b, 0xca); }
 
-// ---- the cell in 16-bit arithmetic.  What an instruction costs on gfx950 depends on its class (profiles/r03_valu_issue_classes.md,
-// tools/microbench/valu_mix.hip): the 16-bit VOP2 forms (v_add/sub/max_i16 ...), v_lshrrev_b32 and v_bitop3_b32 issue every 2 cycles
-// per SIMD once 4 waves are resident, while v_max_i32, v_cmp, v_cndmask, every SDWA/DPP form and every other VOP3 issue every 4.
-// hipcc picks the 32-bit forms for this code, so the cell is spelled out.  Operands are 16-bit two's-complement values in the LOW
-// half of a VGPR; the 16-bit instructions ignore the high half of their inputs and zero it in their result.
-#define BMH_OP16(name, text)                                                                                            \
-	__device__ __forceinline__ int name(int a, int b)                                                                   \
-	{                                                                                                                   \
-		int d;                                                                                                          \
-		asm(text " %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));                                                             \
-		return d;                                                                                                       \
-	}
-BMH_OP16(add16, "v_add_u16")   // a + b
-BMH_OP16(sub16, "v_sub_u16")   // a - b: bit 15 = [a < b] while |a - b| < 32768
-BMH_OP16(max16, "v_max_i16")   // signed
-#undef BMH_OP16
-__device__ __forceinline__ int subk16(int a, int k) // a - k, k wave-uniform (SGPR or inline constant as src0 of v_subrev)
-{
-	int d;
-	asm("v_subrev_u16 %0, %1, %2" : "=v"(d) : "s"(k), "v"(a));
-	return d;
-}
-// H(i-1,j-1) (low half of r) + the score byte B of sc4, sign-extended: low half of the result = M(i,j)
-template <int B> __device__ __forceinline__ int add_score(int sc4, int r)
-{
-	int d;
-	if constexpr (B == 0) asm("v_add_u32_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:WORD_0" : "=v"(d) : "v"(sc4), "v"(r));
-	if constexpr (B == 1) asm("v_add_u32_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:WORD_0" : "=v"(d) : "v"(sc4), "v"(r));
-	if constexpr (B == 2) asm("v_add_u32_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:WORD_0" : "=v"(d) : "v"(sc4), "v"(r));
-	if constexpr (B == 3) asm("v_add_u32_sdwa %0, sext(%1), %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:WORD_0" : "=v"(d) : "v"(sc4), "v"(r));
-	return d;
-}
-// high half of r = max(a, b) (signed 16-bit), low half kept: E(i+1,j) goes in beside the H(i,j) already in r
-__device__ __forceinline__ void max16_into_hi(int &r, int a, int b)
-{
-	asm("v_max_i16_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0" : "+v"(r) : "v"(a), "v"(b));
-}
-
 #ifndef BMH_GL_WAVES64
 #define BMH_GL_WAVES64 3 /* round 3 (16-bit cell): 3 waves per SIMD hold the row loop without scratch traffic; 4 do not (100+ spills) */
 #endif
