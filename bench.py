@@ -537,6 +537,7 @@ def main():
     gbin_ms = np.zeros(3)
     for c in ctxs:
         c.set_kernel_timing(True)
+    cx_ext.extend_bin_ms_sum(reset=True)
     evs = []
     for c in chunks:
         e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -556,6 +557,7 @@ def main():
         e0.record(ss); run_sw(b); e1.record(ss)
         sync_all()
         stage_ms["mate_rescue_sw"] += e0.elapsed_time(e1)
+    ext_bin_ms, ext_bin_launches = cx_ext.extend_bin_ms_sum(reset=True)  # per extension kernel, summed over the fused rounds of all chunks
     for c in ctxs:
         c.set_kernel_timing(False)
 
@@ -648,41 +650,69 @@ def main():
         names = ["round L1: left extensions (extend_lane_kernel<32|64|128> + seed_left_make)", "round L2: left retries at 2w",
                  "round R1: right extensions, h0 = the device's left score", "round R2: right retries at 2w"]
         for k in range(4):
-            kernels.append({"kernel": "seedext " + names[k], "ms": float(round_ms[k]), "launches": n_chunks,
+            kernels.append({"kernel": "seedext " + names[k], "ms": float(round_ms[k]), "launches": n_chunks, "single_kernel": False,
                             "algorithmic_bytes": ext_bytes / 2 if k in (0, 2) else 0.0})
-        gnames = ["global_lane_kernel<64> (ksw_global2 + traceback, w <= 31, 64 tasks/wave)", "global_lane_kernel<96> + <128> (32 <= w <= 47, 48 <= w <= 63)",
+        # the extension kernels themselves (a round is several of them): time per length bin summed over the rounds, HIP events on the
+        # launch streams; the algorithmic bytes of the fused records are split over the bins in proportion to their time
+        ext_names = ["extend_lane_kernel<32, true, false>", "extend_lane_kernel<64, true, false>", "extend_lane_kernel<128, true, false>",
+                     "extend_lanex_kernel<2> / extend_reg_kernel<4> (129-256 columns)", "extend_lanex_kernel<4> (257-512 columns)", "extend_lds_kernel (longer)"]
+        ext_tot = sum(ext_bin_ms) or 1.0
+        for b in range(6):
+            if ext_bin_ms[b] > 0:
+                kernels.append({"kernel": ext_names[b], "ms": float(ext_bin_ms[b]), "launches": max(1, ext_bin_launches), "single_kernel": b < 3,
+                                "algorithmic_bytes": ext_bytes * ext_bin_ms[b] / ext_tot})
+        gnames = ["global_lane_kernel<64, true> (ksw_global2 + traceback, w <= 31, 64 tasks/wave)", "global_lane_kernel<96> + <128> (32 <= w <= 47, 48 <= w <= 63)",
                   "global_kernel (one wave per task: wide bands, long targets)"]
         for b in range(3):
-            kernels.append({"kernel": gnames[b], "ms": float(gbin_ms[b]), "launches": n_chunks, "tasks": int((gbin == b).sum()),
+            kernels.append({"kernel": gnames[b], "ms": float(gbin_ms[b]), "launches": n_chunks, "tasks": int((gbin == b).sum()), "single_kernel": b != 1,
                             "algorithmic_bytes": float(g_bytes[gbin == b].sum())})
-        kernels.append({"kernel": "sw_lane_kernel<80> + second pass (ksw_align2, mate rescue)", "ms": stage_ms["mate_rescue_sw"], "launches": n_swb,
-                        "tasks": n_sw, "algorithmic_bytes": sw_bytes})
+        kernels.append({"kernel": "sw_lane_kernel<80, true, false, false> + second pass (ksw_align2, mate rescue)", "ms": stage_ms["mate_rescue_sw"], "launches": n_swb,
+                        "tasks": n_sw, "algorithmic_bytes": sw_bytes, "single_kernel": False})
         for k in kernels:
             k["avg_launch_ms"] = k["ms"] / k["launches"]
             k["GBps"] = k["algorithmic_bytes"] / (k["ms"] * 1e-3) / 1e9 if k["ms"] > 0 else None
-        # the dominant kernel of the roofline object is ONE kernel (a row of the rocprofv3 summary in profiles/), not a round of the
-        # fused extension, which is three lane kernels and a record kernel: the largest of the entries that are a single kernel
-        dom = max((k for k in kernels if k["kernel"].startswith(("global_lane_kernel", "global_kernel"))), key=lambda k: k["ms"])
-        traffic = None
-        valu = None
+        # the dominant kernel of the roofline object: the ONE kernel (a row of the rocprofv3 summary in profiles/) with the largest total
+        # time in the step -- whichever family it belongs to
+        dom = max((k for k in kernels if k["single_kernel"]), key=lambda k: k["ms"])
+        dom_name = dom["kernel"].split(" (")[0]
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from csrc_sha import csrc_sha
+        tree_sha = csrc_sha(ROOT)
+        traffic = traffic_src = valu = None
+        insts_per_launch = None
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        traffic_src = None
-        if os.path.exists(tpath):  # HBM bytes per launch from rocprofv3 PMC passes of this same command (tools/profile_bench.sh)
+        if os.path.exists(tpath):  # HBM bytes and VALU instructions per launch from rocprofv3 PMC passes of this same command (tools/profile_bench.sh)
             tj = json.load(open(tpath))
-            key = dom["kernel"].split(" ")[0]
-            for kname, v in tj.get("kernels", {}).items():
-                if key.rstrip(">") in kname:
-                    traffic = v.get("hbm_bytes_per_launch")
-                    if v.get("valu_insts_per_launch"):
-                        # what actually bounds the kernel: the VALU issue rate.  A wave64 VALU instruction occupies a SIMD (16
-                        # lanes) for 4 cycles: peak = CUs x 4 SIMDs x clock / 4 wave-instructions/s (MI355X_MICROARCH.md: 256 CUs,
-                        # 2.4 GHz); achieved = SQ_INSTS_VALU per launch (same PMC passes) / this run's launch duration
-                        peak_valu = 256 * 4 * 2.4e9 / 4 / 1e9
-                        ach = v["valu_insts_per_launch"] / (dom["avg_launch_ms"] * 1e-3) / 1e9
-                        valu = {"bound": "valu-issue", "achieved": ach, "peak": peak_valu, "unit": "G wave-instructions/s", "frac": ach / peak_valu,
-                                "valu_insts_per_launch": v["valu_insts_per_launch"],
-                                "note": "the launch shares the chip with the other stages' kernels (3 streams); alone it runs 1.4x faster"}
-                    traffic_src = f"profiles/traffic_latest.json ({tj.get('commit', 'commit not recorded')}; rocprofv3 FETCH_SIZE+WRITE_SIZE passes of this command)"
+            if tj.get("csrc_sha") != tree_sha:
+                traffic_src = (f"profiles/traffic_latest.json was produced from kernel sources {tj.get('csrc_sha', '(unstamped)')}, this tree is {tree_sha}: "
+                               f"not quoted (re-run tools/profile_bench.sh + tools/summarize_prof.py)")
+            else:
+                for kname, v in tj.get("kernels", {}).items():
+                    if kname.replace("bmh::", "").startswith(dom_name):
+                        traffic = v.get("hbm_bytes_per_launch")
+                        insts_per_launch = v.get("valu_insts_per_launch")
+                        traffic_src = f"profiles/traffic_latest.json (kernel sources {tree_sha}; rocprofv3 FETCH_SIZE+WRITE_SIZE and SQ_INSTS_VALU passes of this command, {tj.get('source')})"
+        # what actually bounds these kernels: the vector-instruction issue rate, which on gfx950 depends on the instruction class
+        # (profiles/r03_valu_issue_classes.md: 2 cycles per SIMD for the fast class, 4 for the slow class, measured).  The kernel's own
+        # mix (profiles/r03_valu_mix.json, static count over its DP row loop, same source hash) gives its mix-weighted peak.
+        mpath = os.path.join(ROOT, "profiles", "r03_valu_mix.json")
+        if os.path.exists(mpath):
+            mj = json.load(open(mpath))
+            mk = mj.get("kernels", {}).get(dom_name)
+            if mk and mj.get("csrc_sha") == tree_sha:
+                peak_mix = mk["peak_mix_weighted_Ginst_s"]
+                ach = insts_per_launch / (dom["avg_launch_ms"] * 1e-3) / 1e9 if insts_per_launch else None
+                valu = {"bound": "valu-issue", "kernel": dom_name, "mix": {"fast_2cyc": mk["fast"], "slow_4cyc": mk["slow"], "slow_8cyc": mk["slow8"]},
+                        "cycles_per_instruction_mix_weighted": mk["cycles_per_valu"], "peak_mix_weighted": peak_mix,
+                        "peak_all_slow": 256 * 4 * mj["clock_GHz"] / 4, "peak_all_fast": 256 * 4 * mj["clock_GHz"] / 2,
+                        "achieved": ach, "unit": "G wave-instructions/s", "frac": ach / peak_mix if ach else None,
+                        "valu_insts_per_launch": insts_per_launch, "valu_per_cell_static": mk.get("valu_per_cell"),
+                        "source": "profiles/r03_valu_issue_classes.md (measured classes), profiles/r03_valu_mix.json (this kernel's loop), "
+                                  "SQ_INSTS_VALU from " + (traffic_src or "no PMC file for this tree"),
+                        "note": "the launch shares the chip with the other stages' kernels (3 streams); the peak needs >= 4 resident waves per SIMD for the "
+                                "fast class, the kernel's register count allows fewer (DESIGN.md)"}
+            elif mk:
+                valu = {"skipped": f"profiles/r03_valu_mix.json is from kernel sources {mj.get('csrc_sha')}, this tree is {tree_sha} (python tools/make_valu_mix_profile.py)"}
         metric = "aligned reads/sec (150 bp PE vs hg38) at 1/2/4/8 MI355X; SAM bit-exact vs CPU"
         bpath = os.path.join(ROOT, "BASELINE.json")
         if os.path.exists(bpath):

@@ -118,6 +118,7 @@ def lib():
         L.bmh_last_extend_bin_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.bmh_last_global_bin_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         L.bmh_last_seedext_round_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+        L.bmh_extend_bin_ms_sum.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_int]
         L.bmh_upload_pool.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.bmh_extend_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_int64, C.c_void_p]
         L.bmh_extend_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
@@ -222,6 +223,13 @@ class Context:
         ms = (C.c_float * 6)()
         self._check(lib().bmh_last_extend_bin_ms(self._h, ms))
         return [float(x) for x in ms]
+
+    def extend_bin_ms_sum(self, reset=True):
+        """per-bin kernel time summed over the dispatcher launches since the last reset (timing mode) -> (ms[6], launches)"""
+        ms = (C.c_double * 6)()
+        n = C.c_longlong(0)
+        self._check(lib().bmh_extend_bin_ms_sum(self._h, ms, C.byref(n), 1 if reset else 0))
+        return [float(x) for x in ms], int(n.value)
 
     def last_seedext_round_ms(self):
         ms = (C.c_float * 4)()

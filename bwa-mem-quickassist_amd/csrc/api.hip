@@ -415,6 +415,18 @@ int bmh_last_extend_bin_ms(bmh_ctx_t *ctx, float ms[6])
 	return BMH_OK;
 }
 
+int bmh_extend_bin_ms_sum(bmh_ctx_t *ctx, double ms[6], long long *launches, int reset)
+{
+	if (!ctx || !ms) return BMH_E_ARG;
+	for (int b = 0; b < kExtBins; ++b) ms[b] = ctx->ext_bin_ms_sum[b];
+	if (launches) *launches = ctx->ext_bin_launches;
+	if (reset) {
+		for (int b = 0; b < kExtBins; ++b) ctx->ext_bin_ms_sum[b] = 0.0;
+		ctx->ext_bin_launches = 0;
+	}
+	return BMH_OK;
+}
+
 int bmh_last_seedext_round_ms(bmh_ctx_t *ctx, float ms[4])
 {
 	if (!ctx || !ms) return BMH_E_ARG;

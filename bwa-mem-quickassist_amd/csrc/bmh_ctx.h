@@ -58,6 +58,8 @@ struct bmh_ctx {
 	hipEvent_t ev_join2 = nullptr;
 	hipEvent_t ev_wait = nullptr; // hipEventBlockingSync: what stream_wait() sleeps on in blocking mode
 	bool ev_bin_valid = false;
+	double ext_bin_ms_sum[kExtBinsMax + 1] = {}; // timing mode: per-bin kernel time summed over dispatcher launches (bmh_extend_bin_ms_sum)
+	long long ext_bin_launches = 0;
 	hipEvent_t ev_gbin[4] = {}; // boundaries of the three kernels of a global-alignment launch (64-slot, 128-slot, wave)
 	bool ev_gbin_valid = false;
 	hipEvent_t ev_sround[5] = {}; // boundaries of the four rounds of a fused per-seed launch

@@ -311,6 +311,15 @@ int launch_extend(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_t
 	if (tm) {
 		BMH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
 		ctx->ev_valid = ctx->ev_bin_valid = true;
+		// timing mode is a measurement mode: wait here and add this launch's per-bin durations to the running sums, so that a
+		// caller of the fused per-seed pipeline (four dispatcher launches per call) can attribute its time to kernels
+		BMH_HIP(ctx, hipEventSynchronize(ctx->ev1));
+		for (int b = 0; b < kExtBins; ++b) {
+			float ms = 0.f;
+			if (hipEventElapsedTime(&ms, ctx->ev_bin[b], ctx->ev_bin_end[b]) == hipSuccess && ms > 0.f) ctx->ext_bin_ms_sum[b] += ms;
+			else (void)hipGetLastError();
+		}
+		++ctx->ext_bin_launches;
 	}
 	return BMH_OK;
 }

@@ -95,6 +95,11 @@ __global__ __launch_bounds__(64, B <= 40 ? 3 : B <= 80 ? 2 : 1) void sw_lane_ker
 	constexpr uint32_t TAGMAX = (1u << SC) - 1, SBND = WORD ? 512 : 255;
 	__shared__ uint2 srow[8];              // [t] = {biased scores of target base t against A,C,G,T; against N}
 	__shared__ uint32_t wl[(B / 2) * 64]; // v_perm selectors, two column pairs per dword, [word][lane]
+	// the target, kSwStreamRows rows at a time, one byte per row at [row][lane]: fetched from global memory inside the row loop (under an
+	// exec mask, so the compiler cannot count the load) every row paid an s_waitcnt vmcnt(0) -- a memory round trip plus the drain of
+	// the row-maximum stores in flight (a third of the waves' lifetime in profiles/r03_*)
+	constexpr int kSwStreamRows = 64;
+	__shared__ uint8_t strm[kSwStreamRows * 64];
 	__shared__ uint32_t ml[CORR ? 2 * ((B + 15) / 16) * 64 : 64]; // N / lane-specific padding bits per 16 columns, [2*g16+kind][lane]
 	const int lane = threadIdx.x;
 	if (count && *count == 0) return; // an empty bin (most launches of a small batch are): nothing to set up
@@ -213,7 +218,12 @@ __global__ __launch_bounds__(64, B <= 40 ? 3 : B <= 80 ? 2 : 1) void sw_lane_ker
 			int gmax = 0, te = -1, qe = 0, nrows = 0;
 			uint32_t hdB = 0, fsB = 0, ffB = 0, prevKA = TAGMAX;
 			uint2 rB = make_uint2(0u, 0u);
-			int tn = alive ? swl_tbase(seq, P, 0) : 4;
+			auto fill_stream = [&](int r0) {
+#pragma unroll 4
+				for (int r = 0; r < kSwStreamRows; ++r) strm[r * 64 + lane] = (uint8_t)(alive && r0 + r < tlen ? swl_tbase(seq, P, r0 + r) : 4);
+			};
+			fill_stream(0);
+			int tn = strm[lane];
 			uint32_t K = 0x0c0c0c0cu;
 			int woff = lane;
 			typedef const uint32_t __attribute__((address_space(4))) *sw_ctab_t;
@@ -223,8 +233,8 @@ __global__ __launch_bounds__(64, B <= 40 ? 3 : B <= 80 ? 2 : 1) void sw_lane_ker
 
 			for (int s = 0; __builtin_amdgcn_ballot_w64(alive) != 0; ++s) {
 				const uint2 rA = srow[tn];
-				tn = 4;
-				if (alive && s + 1 < tlen) tn = swl_tbase(seq, P, s + 1);
+				if (((s + 1) & (kSwStreamRows - 1)) == 0) fill_stream(s + 1); // wave-uniform; row s's base is already in rA
+				tn = strm[((s + 1) & (kSwStreamRows - 1)) * 64 + lane];
 				const uint32_t plo = rA.x, phi = rB.x;
 				const uint32_t vN = WORD ? rA.y | rB.y << 16 : rA.y << 8 | rB.y << 24;
 				asm volatile("" : "+v"(K), "+v"(woff), "+s"(xc)); // keeps the row-invariant selector work inside the row loop

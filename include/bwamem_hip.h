@@ -235,6 +235,9 @@ int bmh_set_kernel_timing(bmh_ctx_t *ctx, int enable);
 /* Per-kernel duration of the last extension launch, one entry per query-length bin of the dispatcher:
  * qlen <= 32, <= 64, <= 128, <= 256, <= 512, longer (LDS kernel).  -1 when timing was off. */
 int bmh_last_extend_bin_ms(bmh_ctx_t *ctx, float ms[6]);
+/* With timing on, every dispatcher launch (a fused per-seed call makes four) waits for its kernels and adds their per-bin durations
+ * to running sums: ms[b] = the sum for bin b, *launches (nullable) = dispatcher launches counted; reset != 0 clears the sums. */
+int bmh_extend_bin_ms_sum(bmh_ctx_t *ctx, double ms[6], long long *launches, int reset);
 /* Per-kernel duration of the last global-alignment launch: the 64-slot lane kernel (w <= 31), the 128-slot one (w <= 63),
  * the one-wave-per-task kernel (everything else).  -1 when timing was off. */
 int bmh_last_global_bin_ms(bmh_ctx_t *ctx, float ms[3]);

@@ -51,7 +51,11 @@ def test_bench_prints_one_contract_line_on_the_metric_config():
     st = d["stages_ms_per_step"]
     assert all(st[k] > 0 for k in ("seed_extension", "global_alignment", "mate_rescue_sw"))
     ks = d["roofline"]["kernels"]
-    assert any("round R1" in k["kernel"] for k in ks) and any("global_lane_kernel<64>" in k["kernel"] for k in ks)
+    assert any("round R1" in k["kernel"] for k in ks) and any("global_lane_kernel<64" in k["kernel"] for k in ks)
+    assert any(k["kernel"].startswith("extend_lane_kernel<") and k["ms"] > 0 for k in ks)  # the extension kernels themselves, timed per bin
+    # the dominant kernel is the single kernel with the largest total time, whichever family it is in
+    singles = [k for k in ks if k["single_kernel"]]
+    assert d["roofline"]["kernel"] == max(singles, key=lambda k: k["ms"])["kernel"]
     assert d["config"]["ksw_extend2_calls_per_gpu"] > d["config"]["seeded_reads_per_gpu"]  # left AND right flanks
     pb = d["cpu_baseline_pipeline"]
     if "skipped" not in pb:  # needs oracle/_ref (travels with the tree)

@@ -52,5 +52,8 @@ for k in sorted(acc):
     print()
 if tj:
     commit = os.popen("git -C %s rev-parse --short HEAD 2>/dev/null" % os.path.dirname(os.path.abspath(__file__))).read().strip()
-    json.dump({"source": os.path.basename(d), "commit": commit or "unknown (no git on the GPU box: see the profile's file name)", "kernels": traffic},
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from csrc_sha import csrc_sha
+    json.dump({"source": os.path.basename(d), "commit": commit or "unknown (no git on the GPU box: see the profile's file name)",
+               "csrc_sha": csrc_sha(), "kernels": traffic},
               open(tj, "w"), indent=1)

@@ -4,9 +4,9 @@ profiles/r03_valu_issue_classes.md), and the mix-weighted issue peak that follow
 
     python tools/valu_mix.py bwa-mem-quickassist_amd/csrc/extend_lane.hip 'extend_lane_kernel<128, true, false>' [--json]
 
-The file is compiled to device assembly (hipcc -S --cuda-device-only, gfx950); the hot loop is the span closed by a backward branch that
-holds the most vector instructions with (almost) no global loads in it -- the unrolled DP row loop, not the per-task set-up loop around
-it; every instruction in it is put into one of the classes below.
+The file is compiled to device assembly (hipcc -S --cuda-device-only, gfx950); the hot loop is the span closed by a backward branch that holds
+the most vector instructions with (almost) no global loads in it and a plausible number of instructions per DP cell -- the unrolled DP
+row loop, not the per-task set-up loop around it; every instruction in it is put into one of the classes below.
 
 Measured (one SIMD, >= 2 resident waves, wall clock; cycles at the 2.39 GHz the chip holds under these loads):
   fast  2 cycles  v_add/sub/subrev_u32, and/or/xor/not/mov, lshrrev/ashrrev_b32, 16-bit VOP2 add/sub/max/min/shift, add/sub_u32|u16 clamp,
@@ -95,8 +95,10 @@ def kernels_of(asm):
     return out
 
 
-def hot_loop(body):
-    """the largest backward-branch span: (first, last) line indices"""
+def hot_loop(body, cells=None):
+    """the unrolled DP row loop: of all spans closed by a backward branch the one with the most vector instructions that (a) has (almost)
+    no global loads in it -- not the per-task set-up loop around it -- and (b), when the number of DP cells a trip advances is given,
+    stays under 64 vector instructions per cell (larger spans take in the task loop or the traceback): (first, last) line indices"""
     labels = {}
     for i, l in enumerate(body):
         m = re.match(r"^(\.LBB\d+_\d+):", l)
@@ -109,8 +111,7 @@ def hot_loop(body):
             a = labels[m.group(1)]
             cnt, _ = mix_of(body[a:i + 1])
             valu = sum(cnt.get(c, 0) for c in CYC)
-            # the DP row loop, not the task-setup loop around it: (almost) no global loads inside
-            if cnt.get("vmem", 0) * 100 <= valu and valu > best[2]:
+            if cnt.get("vmem", 0) * 100 <= valu and (not cells or valu <= 64 * cells) and valu > best[2]:
                 best = (a, i, valu)
     return best[0], best[1]
 
@@ -141,7 +142,7 @@ def report(hip, pattern, extra=(), cells=None):
         if pattern and pattern not in d:
             continue
         body = ks[n]
-        a, b = hot_loop(body)
+        a, b = hot_loop(body, cells)
         cnt, ops = mix_of(body[a:b + 1])
         valu = sum(cnt.get(c, 0) for c in CYC)
         cyc = sum(cnt.get(c, 0) * CYC[c] for c in CYC)
