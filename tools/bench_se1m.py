@@ -151,6 +151,7 @@ def main(argv=None):
         dg_tasks = torch.from_numpy(gtasks.view(np.uint8)).to(dev)
         dg_res = torch.zeros(len(gtasks) * pkg.GLB_RES.itemsize, dtype=torch.uint8, device=dev)
         dg_cig = torch.zeros(gwords + 4, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize(dev)  # fills run on torch's current stream, the kernels on the context's
         ctx.set_qcap(int(max(gtasks["qlen"].max(), tasks["qlen"].max())))
         gsteps = max(3, args.steps // 4)
         with torch.cuda.stream(stream):
@@ -196,6 +197,7 @@ def main(argv=None):
         ds_pool = torch.from_numpy(spool).to(dev)
         ds_tasks = torch.from_numpy(stasks.view(np.uint8)).to(dev)
         ds_res = torch.zeros(len(stasks) * pkg.SW_RES.itemsize, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize(dev)
         ssteps = max(3, args.steps // 4)
         with torch.cuda.stream(stream):
             ctx.sw_batch_device(ds_pool.data_ptr(), ds_tasks.data_ptr(), len(stasks), ds_res.data_ptr())
