@@ -196,61 +196,72 @@ def launch_ranks(n, argv):
 
 
 class HostFeed:
-    """--feed host: the step with the PCIe feed inside it.  Task records and sequence pools start in PINNED HOST memory (where the
-    C shim stages them: the reference copies query/target bytes per call at bwamem.c:813-817); each chunk's upload rides a copy stream
-    one chunk ahead of the compute streams into one of two device slots, the kernels run exactly as in the resident step, and every
-    chunk's results (finished regions, global scores, CIGAR words; mate-rescue results) come back to pinned host memory on a third
+    """--feed host: the step with the PCIe feed inside it.  What travels is what the library's drivers ship (host/chain2aln_batch.c,
+    host/reg2cigar_batch.c through the preload shim): per chunk the READS and the task records up, the finished regions, global scores,
+    CIGAR words (16 words of room per task, as host/sam_post.c hands it out) and rescue results down.  The reference windows of the
+    seed records do not travel: they stand for reference bases, which the shim keeps resident in HBM (bmh_ctx_set_pac; here: the
+    windows region of each chunk's pool, uploaded once before the timed region).  The global tasks' target bytes DO travel -- the
+    CIGAR driver still ships decoded windows.  Everything starts in PINNED host memory; each chunk's upload rides a copy
+    stream one chunk ahead of the compute streams, the kernels run exactly as in the resident step, results come back on a third
     stream -- all inside the timed region.  Chunks are numbered globally, so the pipeline keeps running across step boundaries."""
-
     CIGAR_WORDS = 16
 
-    def __init__(self, torch, dev, pkg, host, host_sw, ctxs_of, streams_of):
+    def __init__(self, torch, dev, pkg, tg, host, host_sw, ctxs_of, streams_of):
         self.torch, self.dev = torch, dev
         self.cx_exts, self.cx_glb, self.cx_sw = ctxs_of
         self.s_exts, self.s_glb, self.s_sw = streams_of
         self.h2d, self.d2h = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
         pin = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).pin_memory()
+        dz = lambda nbytes: torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
         self.chunks = []
         for pool, seeds, gpool, gtasks, gwords in host:
-            # CIGAR room as the library's own driver hands it out (host/sam_post.c: 16 words per region, the rare longer CIGAR is redone
-            # with its worst-case room): the generator's worst-case caps would send 20 GB per step back over PCIe for 0.3 GB of words
+            sp, st, rb = tg.split_reads_windows(pool, seeds)  # [all reads | all windows], offsets rewritten
+            d_pool = dz(len(sp))
+            d_pool[rb:].copy_(torch.from_numpy(sp[rb:]))  # the windows = the resident reference: uploaded once, outside the timed region
             gt = gtasks.copy()
             gt["cigar_off"] = np.arange(len(gt), dtype=np.uint32) * HostFeed.CIGAR_WORDS
             gt["cigar_cap"] = HostFeed.CIGAR_WORDS
             gw = len(gt) * HostFeed.CIGAR_WORDS
-            self.chunks.append({"in": [pin(pool), pin(seeds), pin(gpool), pin(gt)], "n": len(seeds), "ng": len(gt), "gwords": gw,
-                                "out": [torch.empty(len(seeds) * pkg.SEED_RES.itemsize, dtype=torch.uint8).pin_memory(),
+            self.chunks.append({"reads": pin(sp[:rb]), "d_pool": d_pool, "in": [pin(st), pin(gpool), pin(gt)], "n": len(st), "ng": len(gt),
+                                "window_bytes": len(sp) - rb,
+                                "out": [torch.empty(len(st) * pkg.SEED_RES.itemsize, dtype=torch.uint8).pin_memory(),
                                         torch.empty(len(gt) * pkg.GLB_RES.itemsize, dtype=torch.uint8).pin_memory(),
                                         torch.empty((gw + 8) * 4, dtype=torch.uint8).pin_memory()]})
-        self.sw = [{"in": [pin(sp), pin(st)], "n": len(st), "out": torch.empty(len(st) * pkg.SW_RES.itemsize, dtype=torch.uint8).pin_memory()}
-                   for sp, st in host_sw]
-        cap_in = [max(c["in"][i].numel() for c in self.chunks) for i in range(4)]
+        self.sw = [{"in": [pin(sp_), pin(st_)], "n": len(st_), "out": torch.empty(len(st_) * pkg.SW_RES.itemsize, dtype=torch.uint8).pin_memory()}
+                   for sp_, st_ in host_sw]
+        cap_in = [max(c["in"][i].numel() for c in self.chunks) for i in range(3)]
         cap_out = [max(c["out"][i].numel() for c in self.chunks) for i in range(3)]
-        dz = lambda nbytes: torch.empty(nbytes, dtype=torch.uint8, device=dev)
         self.slots = [{"in": [dz(b) for b in cap_in], "out": [dz(b) for b in cap_out]} for _ in range(2)]
         self.sw_slot = {"in": [dz(max(b["in"][i].numel() for b in self.sw)) for i in range(2)], "out": dz(max(b["out"].numel() for b in self.sw))}
-        self.h2d_bytes = sum(t.numel() for c in self.chunks for t in c["in"]) + sum(t.numel() for b in self.sw for t in b["in"])
+        self.h2d_bytes = sum(c["reads"].numel() + sum(t.numel() for t in c["in"]) for c in self.chunks) + sum(t.numel() for b in self.sw for t in b["in"])
         self.d2h_bytes = sum(t.numel() for c in self.chunks for t in c["out"]) + sum(b["out"].numel() for b in self.sw)
+        self.resident_window_bytes = sum(c["window_bytes"] for c in self.chunks)
         self.g = 0            # global chunk number
         self.comp_done = {}   # g -> (event on the extension stream, event on the global stream)
         self.back_done = {}   # g -> event on the d2h stream
         self.up_done = {}
         self.sw_free = None   # the rescue slot: free again once its results are back
         self.copy_events = []  # (start, end, bytes) of uploads when instrumented
+        torch.cuda.synchronize(dev)
 
     def _upload(self, g, timed=False):
         torch = self.torch
-        c, slot = self.chunks[g % len(self.chunks)], self.slots[g % 2]
-        for ev in self.comp_done.pop(g - 2, ()):      # the slot's previous chunk has been computed ...
-            self.h2d.wait_event(ev)
+        nc = len(self.chunks)
+        c, slot = self.chunks[g % nc], self.slots[g % 2]
+        for k in {g - 2, g - nc}:  # the slot's previous chunk, and this chunk's own pool one step ago, have been computed
+            for ev in self.comp_done.get(k, ()):
+                self.h2d.wait_event(ev)
+        for k in [k for k in self.comp_done if k < g - max(2, nc)]:
+            del self.comp_done[k]
         with torch.cuda.stream(self.h2d):
             if timed:
                 e0 = torch.cuda.Event(enable_timing=True); e0.record(self.h2d)
+            c["d_pool"][: c["reads"].numel()].copy_(c["reads"], non_blocking=True)
             for src, dst in zip(c["in"], slot["in"]):
                 dst[: src.numel()].copy_(src, non_blocking=True)
             if timed:
                 e1 = torch.cuda.Event(enable_timing=True); e1.record(self.h2d)
-                self.copy_events.append((e0, e1, sum(t.numel() for t in c["in"])))
+                self.copy_events.append((e0, e1, c["reads"].numel() + sum(t.numel() for t in c["in"])))
         ev = torch.cuda.Event(); ev.record(self.h2d)
         self.up_done[g] = ev
 
@@ -260,7 +271,6 @@ class HostFeed:
         g = self.g
         if g not in self.up_done:
             self._upload(g, timed)
-        self._upload(g + 1, timed)  # one chunk ahead of compute
         c, slot = self.chunks[g % len(self.chunks)], self.slots[g % 2]
         k = g % len(self.chunks)
         s_ext, cx_ext = self.s_exts[k % len(self.s_exts)], self.cx_exts[k % len(self.cx_exts)]
@@ -270,11 +280,12 @@ class HostFeed:
             s.wait_event(up)
             if back is not None:
                 s.wait_event(back)
-        cx_ext.seedext_batch_device(slot["in"][0].data_ptr(), slot["in"][1].data_ptr(), c["n"], slot["out"][0].data_ptr())
-        self.cx_glb.global_batch_device(slot["in"][2].data_ptr(), slot["in"][3].data_ptr(), c["ng"], slot["out"][1].data_ptr(), slot["out"][2].data_ptr())
+        cx_ext.seedext_batch_device(c["d_pool"].data_ptr(), slot["in"][0].data_ptr(), c["n"], slot["out"][0].data_ptr())
+        self.cx_glb.global_batch_device(slot["in"][1].data_ptr(), slot["in"][2].data_ptr(), c["ng"], slot["out"][1].data_ptr(), slot["out"][2].data_ptr())
         e_ext, e_glb = torch.cuda.Event(), torch.cuda.Event()
         e_ext.record(s_ext); e_glb.record(self.s_glb)
         self.comp_done[g] = (e_ext, e_glb)
+        self._upload(g + 1, timed)  # one chunk ahead of compute
         self.d2h.wait_event(e_ext); self.d2h.wait_event(e_glb)
         with torch.cuda.stream(self.d2h):
             for src, dst in zip(slot["out"], c["out"]):
@@ -509,7 +520,7 @@ def main():
     if args.feed in ("host", "both"):
         note(f"timed: {rank_ms:.1f} ms per step resident; pinning host buffers for the host-fed steps")
         t0 = time.time()
-        feed = HostFeed(torch, dev, pkg, host, host_sw, (cx_exts, cx_glb, cx_sw), (ext_streams, streams[1 % len(streams)], streams[2 % len(streams)]))
+        feed = HostFeed(torch, dev, pkg, tg, host, host_sw, (cx_exts, cx_glb, cx_sw), (ext_streams, streams[1 % len(streams)], streams[2 % len(streams)]))
         pin_s = time.time() - t0
         for _ in range(max(1, args.warmup)):
             feed.step()
@@ -529,13 +540,14 @@ def main():
         up_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in feed.copy_events)
         up_bytes = sum(b for _, _, b in feed.copy_events)
         streamed = {"value_streamed": reads_all * args.steps / el_s_all, "ms_per_step": el_s_all / args.steps * 1e3, "rank_ms_per_step": rank_ms_s,
-                    "h2d_bytes_per_step": feed.h2d_bytes, "d2h_bytes_per_step": feed.d2h_bytes,
+                    "h2d_bytes_per_step": feed.h2d_bytes, "d2h_bytes_per_step": feed.d2h_bytes, "resident_reference_window_bytes": feed.resident_window_bytes,
                     "h2d_GBps_copy_stream": up_bytes / (up_ms * 1e-3) / 1e9 if up_ms > 0 else None,
                     "pcie_GBps_over_the_step": (feed.h2d_bytes + feed.d2h_bytes) / (rank_ms_s * 1e-3) / 1e9,
                     "pin_s": pin_s,
-                    "what": "task records + sequence pools in pinned host memory, each chunk uploaded one chunk ahead of compute into one of two "
-                            "device slots (copy stream), kernels as in the resident step, finished regions / global scores / CIGAR words / rescue "
-                            "results downloaded to pinned host memory (third stream); all inside the timed region"}
+                    "what": "reads + task records (+ the global tasks' query and target bytes) in pinned host memory, each chunk uploaded one chunk "
+                            "ahead of compute (copy stream), kernels as in the resident step, finished regions / global scores / CIGAR words "
+                            "(16 words of room per task) / rescue results downloaded to pinned host memory (third stream), all inside the timed "
+                            "region; the seed records' reference windows are resident in HBM, as the reference is in the preload shim"}
 
     note(f"timed: {rank_ms:.1f} ms per step" + (f", host-fed {streamed['rank_ms_per_step']:.1f} ms" if streamed else "") + "; instrumented pass")
     # ---- one more, instrumented pass (untimed): HIP events on the launch streams around every stage and every kernel

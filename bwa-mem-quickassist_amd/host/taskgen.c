@@ -306,3 +306,28 @@ int64_t bmh_taskgen_sw(const bmh_taskgen_cfg_t *cfg, const bmh_params_t *p, int6
 	if (pool_used) *pool_used = used;
 	return nt;
 }
+
+/* Re-lays a fused-record pool as [all reads | all windows] (bmh_taskgen_seed puts every read in front of its window) and rewrites the
+ * records' offsets: the windows stand for reference bases, which the preload shim keeps resident in HBM (bmh_ctx_set_pac), so a
+ * host-fed measurement uploads only the first region per batch.  *reads_bytes = size of the reads region (a multiple of 64).
+ * Returns the bytes used in pool_out, 0 if it is too small. */
+size_t bmh_taskgen_split(const uint8_t *pool_in, bmh_seed_task_t *tasks, int64_t n, uint8_t *pool_out, size_t out_cap, size_t *reads_bytes)
+{
+	size_t R = 0, W = 0, q = 0, w;
+	int64_t k;
+	for (k = 0; k < n; ++k) R += (size_t)tasks[k].l_query, W += (size_t)tasks[k].wlen;
+	R = (R + 63) & ~(size_t)63;
+	if (R + W + 16 > out_cap) return 0;
+	w = R;
+	for (k = 0; k < n; ++k) {
+		bmh_seed_task_t *t = &tasks[k];
+		memcpy(pool_out + q, pool_in + t->q_off, (size_t)t->l_query);
+		memcpy(pool_out + w, pool_in + t->t_off, (size_t)t->wlen);
+		t->q_off = q, t->t_off = w;
+		q += (size_t)t->l_query, w += (size_t)t->wlen;
+	}
+	memset(pool_out + q, 0, R - q);
+	memset(pool_out + w, 0, 16);
+	if (reads_bytes) *reads_bytes = R;
+	return w + 16;
+}

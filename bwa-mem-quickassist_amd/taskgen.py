@@ -84,6 +84,22 @@ def generate_seeds(params, n_reads, workload="150bp", seed=7):
     return pool, tasks[:nt].copy()
 
 
+def split_reads_windows(pool, seeds):
+    """(pool', seeds', reads_bytes): the same fused records over a pool laid out [all reads | all windows] -- the windows stand for
+    reference bases resident in HBM, only pool'[:reads_bytes] travels per batch in a host-fed measurement."""
+    from . import SEED_TASK
+    L = _load()
+    L.bmh_taskgen_split.restype = C.c_size_t
+    t = np.ascontiguousarray(seeds, dtype=SEED_TASK).copy()
+    out = np.empty(len(pool) + 128, dtype=np.uint8)
+    rb = C.c_size_t(0)
+    used = L.bmh_taskgen_split(pool.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p), C.c_int64(len(t)),
+                               out.ctypes.data_as(C.c_void_p), C.c_size_t(out.nbytes), C.byref(rb))
+    if not used:
+        raise RuntimeError("split capacity too small")
+    return out[:used], t, int(rb.value)
+
+
 def generate_global(n_reads, workload="150bp", seed=11, wspread=32):
     """Returns (pool, tasks GLB_TASK[], cigar_words) -- one banded global alignment per simulated read."""
     from . import GLB_TASK
