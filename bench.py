@@ -60,7 +60,7 @@ def _fastq_fixed(path, reads, prefix):
     np.concatenate([name, seq, nl, plus, qual, nl], axis=1).tofile(path)
 
 
-def pipeline_baseline(n_reads, genome_bp, threads, batch=8192, noisy=0.3, dut=True):
+def pipeline_baseline(n_reads, genome_bp, threads, batch=8192, noisy=0.3, dut=True, index_log=None):
     """REF and DUT reads/s from the reference's own `[M::mem_process_seqs] Processed N reads in ... real sec` lines
     (bwamem.c:1320-1321; index loading excluded), paired-end, SAM compared (minus @PG)."""
     import kswgen
@@ -74,7 +74,7 @@ def pipeline_baseline(n_reads, genome_bp, threads, batch=8192, noisy=0.3, dut=Tr
     fa = os.path.join(tmp, "ref.fa")
     reflib.write_fasta(fa, "synth", ref)
     t0 = time.time()
-    reflib.build_index(fa)
+    reflib.build_index(fa, index_log)
     t_index = time.time() - t0
     n_pairs, L = n_reads // 2, 150
     ins = rng.integers(250, 450, size=n_pairs)

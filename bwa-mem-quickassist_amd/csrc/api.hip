@@ -218,6 +218,7 @@ int bmh_ctx_create(bmh_ctx_t **out, int device)
 	(void)hipDeviceGetAttribute(&ctx->ncu, hipDeviceAttributeMultiprocessorCount, device);
 	if (ctx->ncu <= 0) ctx->ncu = 256;
 	if (const char *m = getenv("BMH_EXT_PERSIST")) ctx->ext_persist = atoi(m) != 0;
+	if (const char *m = getenv("BMH_EXT_SPLIT96")) ctx->ext_split96 = atoi(m) != 0; // (A/B knob)
 	if (const char *m = getenv("BMH_EXT_GRID_MULT")) ctx->ext_grid_mult = atoi(m) > 0 ? atoi(m) : ctx->ext_grid_mult;
 	if (const char *m = getenv("BMH_EXT_SMALL")) ctx->small_batch = atoi(m) >= 0 ? atoi(m) : ctx->small_batch;
 	if (getenv("BMH_EXT_MODE")) ctx->ext_mode_forced = true;

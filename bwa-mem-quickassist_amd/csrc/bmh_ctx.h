@@ -58,6 +58,7 @@ struct bmh_ctx {
 	hipEvent_t ev_join2 = nullptr;
 	hipEvent_t ev_wait = nullptr; // hipEventBlockingSync: what stream_wait() sleeps on in blocking mode
 	bool ev_bin_valid = false;
+	int ext_split96 = 1; // the 65-128 column bin: tasks of up to 96 columns to extend_lane_kernel<96> (BMH_EXT_SPLIT96=0: all to <128>)
 	double ext_bin_ms_sum[kExtBinsMax + 1] = {}; // timing mode: per-bin kernel time summed over dispatcher launches (bmh_extend_bin_ms_sum)
 	long long ext_bin_launches = 0;
 	hipEvent_t ev_gbin[4] = {}; // boundaries of the three kernels of a global-alignment launch (64-slot, 128-slot, wave)
@@ -161,7 +162,7 @@ int launch_sw_wave(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_sw_task_t *d_t
 int launch_sw_generic(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_sw_task_t *d_tasks, int64_t n,
                       bmh_sw_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, int qcap, int tcap, int wave_cols = 0);
 int launch_extend_lane(bmh_ctx *ctx, int c, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
-                       bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, bool exact);
+                       bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, bool exact, const uint32_t *d_skip = nullptr);
 int launch_extend_reg(bmh_ctx *ctx, int ns, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
                       bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, int max_count = 0, long long grid_cap = 0);
 // wmax: the widest band in stored columns (min(w, qlen)), sizes the wave kernel's direction matrix; wgate: the largest w

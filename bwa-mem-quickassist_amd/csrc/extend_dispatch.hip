@@ -278,7 +278,14 @@ int launch_extend(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_t
 		if (b < 5 && (mode == 1 || (qmax <= qlo && !(mode == 3 && b == 3)))) { // (mode 3 routes long targets of short queries to bin 3)
 			// provably empty bin
 		} else if (b <= 2) {
-			if (mode == 0 || mode == 4) rc = launch_extend_lane(ctx, 32 << b, d_pool, d_tasks, hint.valid ? est[b] : n, d_res, lst, cnt, !hint.valid);
+			if ((mode == 0 || mode == 4) && b == 2 && ctx->ext_split96) {
+				// the 65-128 bin is sorted by query length first (16 buckets of 4 columns): its tasks of up to 96 columns are the head of
+				// the list, and where it ends stands in the sort's cursor array -- the key range of buckets 0-7 closes at key 1023.  They go
+				// to a 96-column instantiation, whose 120 state registers leave room for 3 waves per SIMD (the 128-column one: 2).
+				const uint32_t *n96 = hist + (size_t)2 * kSortKeys + 1023;
+				rc = launch_extend_lane(ctx, 96, d_pool, d_tasks, hint.valid ? est[b] : n, d_res, lst, n96, !hint.valid);
+				if (!rc) rc = launch_extend_lane(ctx, 128, d_pool, d_tasks, hint.valid ? est[b] : n, d_res, lst, cnt, !hint.valid, n96);
+			} else if (mode == 0 || mode == 4) rc = launch_extend_lane(ctx, 32 << b, d_pool, d_tasks, hint.valid ? est[b] : n, d_res, lst, cnt, !hint.valid);
 			else if (mode == 3) rc = launch_extend_grp(ctx, 2 << b, d_pool, d_tasks, n, d_res, lst, cnt);
 			else rc = launch_extend_reg(ctx, b == 2 ? 2 : 1, d_pool, d_tasks, n, d_res, lst, cnt, 0, est[b]);
 		} else if (b == 3) {

@@ -35,7 +35,7 @@ namespace bmh {
 constexpr bool kLaneInterior = BMH_LANE_INTERIOR; // unmasked body for blocks interior to every live lane's interval
 // waves per SIMD the register allocator must leave room for (2nd launch-bounds argument)
 #ifndef BMH_LANE_WAVES
-#define BMH_LANE_WAVES(C) ((C) <= 32 ? 5 : (C) <= 64 ? 4 : 2)
+#define BMH_LANE_WAVES(C) ((C) <= 32 ? 5 : (C) <= 64 ? 4 : (C) <= 96 ? 3 : 2)
 #endif
 
 // per-bit select: mask ? a : b  (one v_bitop3_b32 on gfx950)
@@ -50,7 +50,8 @@ __global__ __launch_bounds__(64, BMH_LANE_WAVES(C)) void extend_lane_kernel(cons
                                                          const uint32_t *__restrict__ order,
                                                          const uint32_t *__restrict__ count, long long n,
                                                          bmh_ext_result_t *__restrict__ out, DevParams P,
-                                                         int *__restrict__ err_flag, long long chunk0)
+                                                         int *__restrict__ err_flag, long long chunk0,
+                                                         const uint32_t *__restrict__ skip)
 {
 	constexpr int NW = C / 32, NQ = C / 4, NB = C / 8;
 	constexpr int INF = 0x7fff;
@@ -74,7 +75,10 @@ __global__ __launch_bounds__(64, BMH_LANE_WAVES(C)) void extend_lane_kernel(cons
 		for (int q = 0; q < 4; ++q) lo |= (uint32_t)(uint8_t)mat_at(P, lane * 5 + q) << (8 * q);
 		srow[lane] = make_uint2(lo, (uint32_t)(uint8_t)mat_at(P, lane * 5 + 4));
 	}
-	const long long cnt = count ? (long long)*count : n;
+	// the kernel's share of the (sorted) list is [skip, count): the 96-column instantiation takes the head of the 65-128 bin
+	// (count = the number of its tasks with qlen <= 96, read from the sort's cursors), the 128-column one the rest (skip = that number)
+	const long long first = skip ? (long long)*skip : 0;
+	const long long cnt = (count ? (long long)*count : n) - first;
 	// persistent grid: a block walks the bin in chunks of 64 tasks with a grid stride (the launcher sizes the grid for
 	// the machine, not for the batch, so an empty or small bin costs a few hundred waves instead of n/64)
 	for (long long base = (chunk0 + (long long)blockIdx.x) * 64; base < cnt; base += LOOP ? (long long)gridDim.x * 64 : cnt) {
@@ -82,7 +86,7 @@ __global__ __launch_bounds__(64, BMH_LANE_WAVES(C)) void extend_lane_kernel(cons
 	// the bin list is sorted ascending (short queries / few rows first); walk it from the back so the most
 	// expensive waves are dispatched first and the cheap ones fill the tail
 	const long long pos = cnt - 1 - (valid ? base + lane : base);
-	const uint32_t idx = order ? order[pos] : (uint32_t)pos;
+	const uint32_t idx = order ? order[first + pos] : (uint32_t)(first + pos);
 
 	const uint4 *tp = (const uint4 *)(tasks + idx);
 	const uint4 ta = tp[0], tb = tp[1];
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(64, BMH_LANE_WAVES(C)) void extend_lane_kernel(cons
 // bin size (exact or an upper bound without a hint).  persist: one strided launch with a capped grid.  Otherwise one
 // chunk per block over the estimate, plus a small strided launch that picks up whatever lies beyond it.
 int launch_extend_lane(bmh_ctx *ctx, int c, const uint8_t *d_pool, const bmh_ext_task_t *d_tasks, int64_t n,
-                       bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, bool exact)
+                       bmh_ext_result_t *d_res, const uint32_t *d_order, const uint32_t *d_count, bool exact, const uint32_t *d_skip)
 {
 	if (n <= 0) return BMH_OK;
 	const bool sym = ctx->dev.o_del + ctx->dev.e_del == ctx->dev.o_ins + ctx->dev.e_ins;
@@ -271,7 +275,7 @@ int launch_extend_lane(bmh_ctx *ctx, int c, const uint8_t *d_pool, const bmh_ext
 	const long long cap = ext_resident_waves(ctx, BMH_LANE_WAVES(c)) * ctx->ext_grid_mult;
 #define BMH_LAUNCH_LANE2(CC, SY, LP, GRID, C0)                                                                          \
 	hipLaunchKernelGGL((extend_lane_kernel<CC, SY, LP>), dim3((unsigned)(GRID)), dim3(64), 0, ctx->stream, d_pool, d_tasks,  \
-	                   d_order, d_count, (long long)n, d_res, ctx->dev, ctx->d_err, (long long)(C0))
+	                   d_order, d_count, (long long)n, d_res, ctx->dev, ctx->d_err, (long long)(C0), d_skip)
 #define BMH_LAUNCH_LANE(CC, LP, GRID, C0)                                                                               \
 	do {                                                                                                                \
 		if (sym) BMH_LAUNCH_LANE2(CC, true, LP, GRID, C0);                                                              \
@@ -282,6 +286,7 @@ int launch_extend_lane(bmh_ctx *ctx, int c, const uint8_t *d_pool, const bmh_ext
 		switch (c) {                                                                                                    \
 		case 32: BMH_LAUNCH_LANE(32, LP, GRID, C0); break;                                                              \
 		case 64: BMH_LAUNCH_LANE(64, LP, GRID, C0); break;                                                              \
+		case 96: BMH_LAUNCH_LANE(96, LP, GRID, C0); break;                                                              \
 		case 128: BMH_LAUNCH_LANE(128, LP, GRID, C0); break;                                                            \
 		default: return BMH_E_ARG;                                                                                      \
 		}                                                                                                               \
