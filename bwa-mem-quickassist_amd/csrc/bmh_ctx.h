@@ -58,7 +58,10 @@ struct bmh_ctx {
 	hipEvent_t ev_join2 = nullptr;
 	hipEvent_t ev_wait = nullptr; // hipEventBlockingSync: what stream_wait() sleeps on in blocking mode
 	bool ev_bin_valid = false;
-	int ext_split96 = 1; // the 65-128 column bin: tasks of up to 96 columns to extend_lane_kernel<96> (BMH_EXT_SPLIT96=0: all to <128>)
+	int ext_split96 = 0; // BMH_EXT_SPLIT96=1: the 65-128 column bin sends its tasks of up to 96 columns to extend_lane_kernel<96> (3 waves/SIMD).
+	                     // Built, bit-exact, and measured level with one kernel for the bin (20 M-read step: extension 83.4 ms either way; a
+	                     // 1 M-read batch 3.55 against 3.83 ms): per launch the bin holds 4-8 k waves, and two kernels of 1.4 and 0.6 chip-loads
+	                     // lose to wave quantisation what the third resident wave wins
 	double ext_bin_ms_sum[kExtBinsMax + 1] = {}; // timing mode: per-bin kernel time summed over dispatcher launches (bmh_extend_bin_ms_sum)
 	long long ext_bin_launches = 0;
 	hipEvent_t ev_gbin[4] = {}; // boundaries of the three kernels of a global-alignment launch (64-slot, 128-slot, wave)
