@@ -328,8 +328,9 @@ def main():
     ap.add_argument("--workload", default="pe10m", choices=["pe10m", "se1m"])
     ap.add_argument("--shape", default="150bp", choices=["150bp", "250bp", "mixed100-300"], help="read model of the task generator")
     ap.add_argument("--pairs", type=int, default=10_000_000, help="read pairs per GPU per step (pe10m)")
-    ap.add_argument("--chunk-reads", type=int, default=4_000_000,
-                    help="reads per streamed chunk (measured: 20 chunks of 1 M 215 ms per step, 10 of 2 M 208, 5 of 4 M 203, 2 of 10 M 203.5)")
+    ap.add_argument("--chunk-reads", type=int, default=10_000_000,
+                    help="reads per streamed chunk (round 3: 10 x 2 M 178.1 ms per step, 5 x 4 M 178.2, 2 x 10 M 172.6, 1 x 20 M 178.3 -- more waves per "
+                         "launch, fewer half-empty tails; round 2: 20 x 1 M 215, 5 x 4 M 203)")
     ap.add_argument("--global-per-read", type=float, default=0.85, help="ksw_global2 tasks per read (measured, SURVEY.md §8a2)")
     ap.add_argument("--rescue-rate", type=float, default=0.06, help="ksw_align2 mate-rescue tasks per pair (measured 0.02-0.11)")
     ap.add_argument("--rescue-batch", type=int, default=1_000_000, help="mate-rescue tasks are collected over chunks into batches of up to this many")

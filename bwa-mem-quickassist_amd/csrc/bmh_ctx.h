@@ -58,10 +58,10 @@ struct bmh_ctx {
 	hipEvent_t ev_join2 = nullptr;
 	hipEvent_t ev_wait = nullptr; // hipEventBlockingSync: what stream_wait() sleeps on in blocking mode
 	bool ev_bin_valid = false;
-	int ext_split96 = 0; // BMH_EXT_SPLIT96=1: the 65-128 column bin sends its tasks of up to 96 columns to extend_lane_kernel<96> (3 waves/SIMD).
-	                     // Built, bit-exact, and measured level with one kernel for the bin (20 M-read step: extension 83.4 ms either way; a
-	                     // 1 M-read batch 3.55 against 3.83 ms): per launch the bin holds 4-8 k waves, and two kernels of 1.4 and 0.6 chip-loads
-	                     // lose to wave quantisation what the third resident wave wins
+	int ext_split96 = 1; // the 65-128 column bin sends its tasks of up to 96 columns to extend_lane_kernel<96> (3 waves/SIMD); BMH_EXT_SPLIT96=0:
+	                     // one kernel for the bin.  Measured: a 1 M-read batch 3.55 against 3.83 ms; the 20 M-read step's extension stage level at
+	                     // 4 M-read chunks (83.4 ms: the bin's 4-8 k waves per launch lose to wave quantisation what the third resident wave wins),
+	                     // 76.1 against 80.3 ms at 10 M-read chunks
 	double ext_bin_ms_sum[kExtBinsMax + 1] = {}; // timing mode: per-bin kernel time summed over dispatcher launches (bmh_extend_bin_ms_sum)
 	long long ext_bin_launches = 0;
 	hipEvent_t ev_gbin[4] = {}; // boundaries of the three kernels of a global-alignment launch (64-slot, 128-slot, wave)

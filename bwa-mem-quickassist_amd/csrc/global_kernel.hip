@@ -210,6 +210,8 @@ __global__ __launch_bounds__(64) void global_kernel(const uint8_t *__restrict__ 
 // bin 0: w <= 31  -> global_lane_kernel<64>   (64 tasks per wave, band-relative registers)
 // bin 1: w <= 63  -> global_lane_kernel<128>
 // bin 3: 32 <= w <= 47 -> global_lane_kernel<96>
+//        (an 80-slot instantiation for bands of 32-39 only pays at three waves per SIMD, and under 168 VGPRs its row loop spills
+//        49 registers: not used)
 // bin 2: wider bands, targets longer than the lane kernels' direction slab, or scores that could leave the
 //        16-bit range -> global_kernel (one wave per task, int32 in LDS)
 // Bins and the order inside them (by row count) come from the same device-side counting sort as the extension path.
@@ -228,7 +230,9 @@ __global__ __launch_bounds__(256) void glb_sort_hist_kernel(const bmh_glb_task_t
 		const int qlen = tasks[idx].qlen, tlen = tasks[idx].tlen, w = tasks[idx].w;
 		const int worst = P.o_del + P.o_ins + emax * (qlen + tlen) + smax * max(qlen, tlen); // |score| bound of any cell
 		int bin = 2;
-		if (lane_ok && tlen <= rows_cap && worst < 12000 && w >= 0) bin = w <= 31 ? 0 : w <= 47 ? 3 : (w <= 63 ? 1 : 2);
+		// (the lane kernels take the sign of 16-bit differences such as m - e - o_del: with |m|, |e| < 12000 and the -16384 sentinel that
+		// stays inside +-32767 as long as the gap-open penalties are not absurd)
+		if (lane_ok && tlen <= rows_cap && worst < 12000 && P.o_del + P.o_ins < 4000 && w >= 0) bin = w <= 31 ? 0 : w <= 47 ? 3 : (w <= 63 ? 1 : 2);
 		// inside a lane bin: rows first (lanes of a wave run until their longest target ends), then band width (a wave
 		// computes and stores the 8-slot blocks that ANY of its lanes needs, and its lanes' tracebacks share cache lines
 		// when they sit in the same block)

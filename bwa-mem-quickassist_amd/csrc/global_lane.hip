@@ -48,13 +48,14 @@ __device__ __forceinline__ int sel3(int mask, int a, int b) { return __builtin_a
 #define BMH_GL_WAVES96 2
 #endif
 
+
 template <int C, bool FAST>
 __global__ __launch_bounds__(64, (C <= 64 ? BMH_GL_WAVES64 : C <= 96 ? BMH_GL_WAVES96 : BMH_GL_WAVES128)) void global_lane_kernel(
     const uint8_t *__restrict__ pool, const bmh_glb_task_t *__restrict__ tasks, const uint32_t *__restrict__ order,
     const uint32_t *__restrict__ count, long long n, bmh_glb_result_t *__restrict__ out, uint32_t *__restrict__ cigar_pool,
     DevParams P, uint32_t *__restrict__ zslab, int rows_cap, int *__restrict__ err_flag)
 {
-	constexpr int NW = C / 32, NQ = C / 4, NB = C / 8;
+	constexpr int NW = (C + 31) / 32, NQ = C / 4, NB = C / 8;
 	__shared__ uint2 srow[8];
 	extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[]; // max(C, kStreamRows) x 64 bytes: the window staging, then the per-row stream
 	const int lane = threadIdx.x;
@@ -230,21 +231,25 @@ __global__ __launch_bounds__(64, (C <= 64 ? BMH_GL_WAVES64 : C <= 96 ? BMH_GL_WA
 			// score = eh[qlen].h after the LAST row of a lane = H(tlen-1, qlen-1), ksw.c:565: slot qlen-tlen+w of that row.
 			// Picked up right here because the registers of a finished lane are refilled by the rows other lanes still run.
 			if (__builtin_amdgcn_ballot_w64(live && i == tlen - 1)) {
-				// register number ss picked by a binary tree of selects on the bits of ss (C-1 selects and log2 C compares; a compare per
+				// register number ss picked by binary trees of selects on the bits of ss (C selects and a few compares; a compare per
 				// register, hoisted out of the row loop by the compiler, used to cost 2 SGPRs per slot)
 				const int ss = qlen - tlen + w;
-				constexpr int CP = C <= 64 ? 64 : 128;
-				int T[CP / 2];
+				int pick = 0;
 #pragma unroll
-				for (int k = 0; k < CP / 2; ++k) {
-					const int a0 = 2 * k < C ? R[2 * k] : 0, a1 = 2 * k + 1 < C ? R[2 * k + 1] : 0;
-					T[k] = (ss & 1) ? a1 : a0;
+				for (int c0 = 0; c0 < C; c0 += 32) { // 32 slots at a time (16 temporaries), then the chunk by the high bits of ss
+					int T[16];
+#pragma unroll
+					for (int k = 0; k < 16; ++k) {
+						const int a0 = c0 + 2 * k < C ? R[c0 + 2 * k] : 0, a1 = c0 + 2 * k + 1 < C ? R[c0 + 2 * k + 1] : 0;
+						T[k] = (ss & 1) ? a1 : a0;
+					}
+#pragma unroll
+					for (int bit = 1, len = 8; len >= 1; ++bit, len >>= 1)
+#pragma unroll
+						for (int k = 0; k < len; ++k) T[k] = (ss >> bit & 1) ? T[2 * k + 1] : T[2 * k];
+					pick = (ss >> 5) == c0 / 32 ? T[0] : pick;
 				}
-#pragma unroll
-				for (int bit = 1, len = CP / 4; len >= 1; ++bit, len >>= 1)
-#pragma unroll
-					for (int k = 0; k < len; ++k) T[k] = (ss >> bit & 1) ? T[2 * k + 1] : T[2 * k];
-				if (live && i == tlen - 1 && ss >= 0 && ss < C) score = (int)(int16_t)(T[0] & 0xffff);
+				if (live && i == tlen - 1 && ss >= 0 && ss < C) score = (int)(int16_t)(pick & 0xffff);
 			}
 			// slide the query window by one base (row i+1 looks at q[i+1-w+s])
 #pragma unroll
