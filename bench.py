@@ -688,12 +688,12 @@ def main():
                             "algorithmic_bytes": ext_bytes / 2 if k in (0, 2) else 0.0})
         # the extension kernels themselves (a round is several of them): time per length bin summed over the rounds, HIP events on the
         # launch streams; the algorithmic bytes of the fused records are split over the bins in proportion to their time
-        ext_names = ["extend_lane_kernel<32, true, false>", "extend_lane_kernel<64, true, false>", "extend_lane_kernel<128, true, false>",
+        ext_names = ["extend_lane_kernel<32, true, false>", "extend_lane_kernel<64, true, false>", "extend_lane_kernel<96, true, false> + <128, true, false> (65-128 columns)",
                      "extend_lanex_kernel<2> / extend_reg_kernel<4> (129-256 columns)", "extend_lanex_kernel<4> (257-512 columns)", "extend_lds_kernel (longer)"]
         ext_tot = sum(ext_bin_ms) or 1.0
         for b in range(6):
             if ext_bin_ms[b] > 0:
-                kernels.append({"kernel": ext_names[b], "ms": float(ext_bin_ms[b]), "launches": max(1, ext_bin_launches), "single_kernel": b < 3,
+                kernels.append({"kernel": ext_names[b], "ms": float(ext_bin_ms[b]), "launches": max(1, ext_bin_launches), "single_kernel": b < 2,
                                 "algorithmic_bytes": ext_bytes * ext_bin_ms[b] / ext_tot})
         gnames = ["global_lane_kernel<64, true> (ksw_global2 + traceback, w <= 31, 64 tasks/wave)", "global_lane_kernel<96> + <128> (32 <= w <= 47, 48 <= w <= 63)",
                   "global_kernel (one wave per task: wide bands, long targets)"]

@@ -14,6 +14,7 @@ from csrc_sha import csrc_sha
 KERNELS = [  # file, demangled-name pattern, DP cells one trip of the hot loop advances per lane
     ("extend_lane.hip", "extend_lane_kernel<32, true, false>", 32),
     ("extend_lane.hip", "extend_lane_kernel<64, true, false>", 64),
+    ("extend_lane.hip", "extend_lane_kernel<96, true, false>", 96),
     ("extend_lane.hip", "extend_lane_kernel<128, true, false>", 128),
     ("global_lane.hip", "global_lane_kernel<64, true>", 64),
     ("global_lane.hip", "global_lane_kernel<96, true>", 96),
