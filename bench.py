@@ -187,7 +187,8 @@ def launch_ranks(n, argv):
         except subprocess.TimeoutExpired:
             p.kill()  # exactly the process started above
             rcs.append(p.wait())
-    sys.stdout.write(out.decode())
+    for line in out.decode().splitlines():  # rank 0's JSON line alone on stdout; anything a library printed there (gloo does) to stderr
+        print(line, file=sys.stdout if line.startswith("{") else sys.stderr)
     sys.stdout.flush()
     bad = [rc for rc in rcs if rc != 0]
     if bad:
