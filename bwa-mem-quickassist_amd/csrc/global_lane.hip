@@ -176,8 +176,8 @@ __global__ __launch_bounds__(64, (C <= 64 ? BMH_GL_WAVES64 : C <= 96 ? BMH_GL_WA
 				// Direction state, 4 bits per cell, as the SIGN BITS of four differences (ksw.c:547-561):
 				//   b1 = [m < e]  b2 = [max(m,e) < f]            -> d = b2 ? 2 : b1
 				//   b3 = [e - e_del > m - oe_del] (E continues)    b4 = [f - e_ins > m - oe_ins] (F continues)
-				// b1,b2 of cell c end up in bits 2c+1, 2c of the block's dword, b3,b4 in bits 16+2c+1, 16+2c: two 16-bit
-				// shift registers (dz12, dz34) take two bits per cell at their top and move down two places per cell.
+				// b1..b4 of cell c end up in bit c of bytes 0..3 of the block's dword: two shift registers (dz12, dz34; fresh per block) take one
+				// bit per cell at the top of each of their two bytes and move down one place per cell.
 				int dz12 = 0, dz34 = 0;
 				auto cells = [&](auto MASKED) {
 #pragma unroll
@@ -196,10 +196,11 @@ __global__ __launch_bounds__(64, (C <= 64 ? BMH_GL_WAVES64 : C <= 96 ? BMH_GL_WA
 							const int x3 = sub16(t1, e2);
 							const int t2 = oe_ins == oe_del ? t1 : subk16(m, oe_ins), f2 = subk16(f, e_ins); // ksw.c:557-560
 							const int x4 = sub16(t2, f2);
-							const int z12 = __builtin_amdgcn_bitop3_b32(0x8000, x1, (int)((unsigned)x2 >> 1), 0xca);
-							const int z34 = __builtin_amdgcn_bitop3_b32(0x8000, x3, (int)((unsigned)x4 >> 1), 0xca);
-							dz12 = __builtin_amdgcn_bitop3_b32((int)((unsigned)dz12 >> 2), z12, 0xc000, 0xf8); // a | (b & c)
-							dz34 = __builtin_amdgcn_bitop3_b32((int)((unsigned)dz34 >> 2), z34, 0xc000, 0xf8);
+							// the high bytes of two differences side by side (one v_perm), their sign bits into bit 7 of byte 0 and of byte 1
+							const int z12 = (int)__builtin_amdgcn_perm((unsigned)x1, (unsigned)x2, 0x0c0c0105u);
+							const int z34 = (int)__builtin_amdgcn_perm((unsigned)x3, (unsigned)x4, 0x0c0c0105u);
+							dz12 = __builtin_amdgcn_bitop3_b32((int)((unsigned)dz12 >> 1), z12, 0x8080, 0xf8); // a | (b & c)
+							dz34 = __builtin_amdgcn_bitop3_b32((int)((unsigned)dz34 >> 1), z34, 0x8080, 0xf8);
 							// register s <- {H(i,j) for the next row's diagonal, E(i+1,j) for the next row's slot s-1}
 							if constexpr (decltype(MASKED)::value) {
 								const int actv = (am[s / 32] << (31 - s % 32)) >> 31;
@@ -292,9 +293,9 @@ __global__ __launch_bounds__(64, (C <= 64 ? BMH_GL_WAVES64 : C <= 96 ? BMH_GL_WA
 					}
 				}
 				if (act) {
-					const uint32_t dzw = strip[(ctop - ti) * 64 + lane] >> (2 * (s & 7));
-					// bits 1,0 = [m < e], [max(m,e) < f]; bits 17,16 = E continues, F continues (see the fill)
-					which = which == 0 ? ((dzw & 1) ? 2 : (int)(dzw >> 1 & 1)) : which == 1 ? (int)(dzw >> 17 & 1) : (int)(dzw >> 15 & 2);
+					const uint32_t dzw = strip[(ctop - ti) * 64 + lane] >> (s & 7);
+					// bit 0 = [m < e], bit 8 = [max(m,e) < f], bit 16 = E continues, bit 24 = F continues (see the fill)
+					which = which == 0 ? ((dzw >> 8 & 1) ? 2 : (int)(dzw & 1)) : which == 1 ? (int)(dzw >> 16 & 1) : (int)(dzw >> 23 & 2);
 					const int op = which == 0 ? 0 : (which == 1 ? 2 : 1);
 					if (last_len > 0 && op == last_op) ++last_len; // ksw.c:489-499
 					else {
