@@ -239,14 +239,26 @@ __global__ __launch_bounds__(64, B <= 40 ? 3 : B <= 80 ? 2 : 1) void sw_lane_ker
 				const uint32_t vN = WORD ? rA.y | rB.y << 16 : rA.y << 8 | rB.y << 24;
 				asm volatile("" : "+v"(K), "+v"(woff), "+s"(xc)); // keeps the row-invariant selector work inside the row loop
 				uint32_t fs = fsB << 16, ff = ffB << 16, key = 0, hlast = hdB << 16;
+				// the per-column subtrahend table comes through the scalar cache, one block (16 dwords) AHEAD of its use and issued from the
+				// middle of the previous block: loaded where it is used, every block started with an s_waitcnt on a scalar-cache round trip
+				// (ten per DP row), and issued next to an LDS read it is waited for with it (lgkmcnt counts both)
+				uint32_t XT[2][16]; // block b reads XT[b & 1] and fills XT[(b + 1) & 1]: no copies (they would be hoisted to just behind the load)
+#pragma unroll
+				for (int k = 0; k < 16; ++k) XT[0][k] = xc[k];
 #pragma unroll
 				for (int b = 0; b < NB; ++b) {
 					if (b >= nb) continue;
 					{
 						const bool flagged = CORR && ((bflag >> b) & 1);
+						// the block's four selector words, read together at its start (read where they are used, each read is followed by an
+						// s_waitcnt that also waits for the scalar-cache prefetch below)
+						uint32_t WS[4];
+#pragma unroll
+						for (int k = 0; k < 4; ++k) WS[k] = wl[(4 * b + k) * 64 + woff];
+						__builtin_amdgcn_sched_barrier(0);
 						// S'(A) << 8 | S'(B) << 24 of column pair c of the block: one v_perm over {row s scores, row s-1 scores}
 						auto subst = [&](int c) {
-							const uint32_t sel = __builtin_amdgcn_perm(wl[(4 * b + c / 2) * 64 + woff], K,
+							const uint32_t sel = __builtin_amdgcn_perm(WS[c / 2], K,
 							                                           WORD ? ((c & 1) ? 0x00070006u : 0x00050004u) : ((c & 1) ? 0x07000600u : 0x05000400u));
 							uint32_t sp = __builtin_amdgcn_perm(phi, plo, sel);
 							if (CORR && flagged) { // N columns score mat[t][4]; padding the other lanes do not share scores 0
@@ -266,7 +278,13 @@ __global__ __launch_bounds__(64, B <= 40 ? 3 : B <= 80 ? 2 : 1) void sw_lane_ker
 #pragma unroll
 						for (int c = 0; c < 8; ++c) {
 							const int jj = 8 * b + c;
-							const uint32_t xsh = xc[2 * jj], xseg = xc[2 * jj + 1];
+							if (c == 5 && b + 1 < NB) { // behind the block's LDS waits (lgkmcnt counts both): six cells for the scalar cache to answer
+								__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+								for (int k = 0; k < 16; ++k) XT[(b + 1) & 1][k] = xc[16 * (b + 1) + k];
+								__builtin_amdgcn_sched_barrier(0);
+							}
+							const uint32_t xsh = XT[b & 1][2 * c], xseg = XT[b & 1][2 * c + 1];
 							const uint32_t m = pk_subs(a, xsh);                  // ksw.c:149-150
 							const uint32_t hp = pk_max(pk_max(m, E[jj]), fs);          // ksw.c:151-153
 							const uint32_t h = pk_max(hp, ff);                          // lazy F, ksw.c:165-176
