@@ -283,7 +283,7 @@ int launch_extend(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_ext_task_t *d_t
 				// the list, and where it ends stands in the sort's cursor array -- the key range of buckets 0-7 closes at key 1023.  They go
 				// to a 96-column instantiation, whose 120 state registers leave room for 3 waves per SIMD (the 128-column one: 2).
 				const uint32_t *n96 = hist + (size_t)2 * kSortKeys + 1023;
-				rc = launch_extend_lane(ctx, 96, d_pool, d_tasks, hint.valid ? est[b] : n, d_res, lst, n96, !hint.valid);
+				rc = launch_extend_lane(ctx, 96, d_pool, d_tasks, hint.valid ? est[b] : n, d_res, lst, n96, true); // (no pick-up launch: see `rem` in the kernel)
 				if (!rc) rc = launch_extend_lane(ctx, 128, d_pool, d_tasks, hint.valid ? est[b] : n, d_res, lst, cnt, !hint.valid, n96);
 			} else if (mode == 0 || mode == 4) rc = launch_extend_lane(ctx, 32 << b, d_pool, d_tasks, hint.valid ? est[b] : n, d_res, lst, cnt, !hint.valid);
 			else if (mode == 3) rc = launch_extend_grp(ctx, 2 << b, d_pool, d_tasks, n, d_res, lst, cnt);

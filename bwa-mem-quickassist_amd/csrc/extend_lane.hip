@@ -75,10 +75,18 @@ __global__ __launch_bounds__(64, BMH_LANE_WAVES(C)) void extend_lane_kernel(cons
 		for (int q = 0; q < 4; ++q) lo |= (uint32_t)(uint8_t)mat_at(P, lane * 5 + q) << (8 * q);
 		srow[lane] = make_uint2(lo, (uint32_t)(uint8_t)mat_at(P, lane * 5 + 4));
 	}
-	// the kernel's share of the (sorted) list is [skip, count): the 96-column instantiation takes the head of the 65-128 bin
-	// (count = the number of its tasks with qlen <= 96, read from the sort's cursors), the 128-column one the rest (skip = that number)
-	const long long first = skip ? (long long)*skip : 0;
-	const long long cnt = (count ? (long long)*count : n) - first;
+	// The kernel's share of the (sorted) list: [0, count) without `skip`.  The 96-column instantiation takes the head of the 65-128 bin
+	// (count = the number of its tasks with qlen <= 96, read from the sort's cursors), the 128-column one the rest: [skip, count) with
+	// skip = that number.  The head is launched WITHOUT the strided pick-up launch -- an empty grid between two full ones still queues for
+	// wave slots behind whatever runs on the other streams, 5-35 ms in the 100-300 bp shape -- so when the estimate `n` fell short of the
+	// head (its one-chunk-per-block grid walks from the back and reached [skip - 64*ceil(n/64), skip)) the `rem` entries at the front
+	// are this launch's to do as well: its positions [0, rem) are those, [rem, cnt) map to [skip, count).
+	long long first = 0, rem = 0;
+	if (skip) {
+		first = (long long)*skip;
+		rem = max(first - (((n + 63) >> 6) << 6), 0LL);
+	}
+	const long long cnt = (count ? (long long)*count : n) - first + rem;
 	// persistent grid: a block walks the bin in chunks of 64 tasks with a grid stride (the launcher sizes the grid for
 	// the machine, not for the batch, so an empty or small bin costs a few hundred waves instead of n/64)
 	for (long long base = (chunk0 + (long long)blockIdx.x) * 64; base < cnt; base += LOOP ? (long long)gridDim.x * 64 : cnt) {
@@ -86,7 +94,8 @@ __global__ __launch_bounds__(64, BMH_LANE_WAVES(C)) void extend_lane_kernel(cons
 	// the bin list is sorted ascending (short queries / few rows first); walk it from the back so the most
 	// expensive waves are dispatched first and the cheap ones fill the tail
 	const long long pos = cnt - 1 - (valid ? base + lane : base);
-	const uint32_t idx = order ? order[first + pos] : (uint32_t)(first + pos);
+	const long long lp = pos < rem ? pos : pos + (first - rem);
+	const uint32_t idx = order ? order[lp] : (uint32_t)lp;
 
 	const uint4 *tp = (const uint4 *)(tasks + idx);
 	const uint4 ta = tp[0], tb = tp[1];
@@ -273,9 +282,11 @@ int launch_extend_lane(bmh_ctx *ctx, int c, const uint8_t *d_pool, const bmh_ext
 	const bool sym = ctx->dev.o_del + ctx->dev.e_del == ctx->dev.o_ins + ctx->dev.e_ins;
 	const long long chunks = (n + 63) / 64;
 	const long long cap = ext_resident_waves(ctx, BMH_LANE_WAVES(c)) * ctx->ext_grid_mult;
+	// what the kernel takes for the reach of the head launch (see `rem` there): a persistent head grid reached everything
+	const long long n_head = ctx->ext_persist && d_skip ? (1LL << 40) : (long long)n;
 #define BMH_LAUNCH_LANE2(CC, SY, LP, GRID, C0)                                                                          \
 	hipLaunchKernelGGL((extend_lane_kernel<CC, SY, LP>), dim3((unsigned)(GRID)), dim3(64), 0, ctx->stream, d_pool, d_tasks,  \
-	                   d_order, d_count, (long long)n, d_res, ctx->dev, ctx->d_err, (long long)(C0), d_skip)
+	                   d_order, d_count, n_head, d_res, ctx->dev, ctx->d_err, (long long)(C0), d_skip)
 #define BMH_LAUNCH_LANE(CC, LP, GRID, C0)                                                                               \
 	do {                                                                                                                \
 		if (sym) BMH_LAUNCH_LANE2(CC, true, LP, GRID, C0);                                                              \
