@@ -61,6 +61,10 @@ CIGAR_REQ = np.dtype([("read", "<i4"), ("qb", "<i4"), ("qe", "<i4"), ("pad", "<i
                       ("truesc", "<i4"), ("reg_w", "<i4")])
 CIGAR_RES = np.dtype([("score", "<i4"), ("n_cigar", "<i4"), ("NM", "<i4"), ("tries", "<i4"), ("cigar_off", "<u4"),
                       ("md_off", "<u4"), ("md_len", "<u4"), ("rsv", "<u4")])
+BMH_REGION_CIGAR_CUT, BMH_REGION_MD_CUT = 1, 2
+REGION_REQ = np.dtype([("q_src", "<u8"), ("rb", "<i8"), ("o_off", "<u8"), ("ql", "<i4"), ("tl", "<i4"), ("truesc", "<i4"),
+                       ("task", "<i4", (3,))])
+REGION_RES = np.dtype([("score", "<i4"), ("n_cigar", "<i4"), ("tries", "<i4"), ("NM", "<i4"), ("md_len", "<i4"), ("flags", "<u4")])
 ALNREG = np.dtype([("rb", "<i8"), ("re", "<i8"), ("qb", "<i4"), ("qe", "<i4"), ("score", "<i4"),
                    ("truesc", "<i4"), ("sub", "<i4"), ("csub", "<i4"), ("sub_n", "<i4"),
                    ("w", "<i4"), ("seedcov", "<i4"), ("secondary", "<i4"), ("hash", "<u8")])
@@ -144,6 +148,9 @@ def lib():
         L.bmh_chain2aln_batch.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p]
         L.bmh_driver_stats.argtypes = [C.c_void_p, C.c_void_p]
+        L.bmh_region_cigar_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64,
+                                             C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.bmh_region_cigar_batch.restype = C.c_int
         L.bmh_reg2cigar_batch.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                           C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
         _lib = L
@@ -276,6 +283,20 @@ class Context:
         self._check(lib().bmh_global_batch(self._h, _ptr(pool), pool.nbytes, _ptr(tasks), len(tasks), _ptr(res),
                                            _ptr(cig), int(cigar_words)))
         return res, cig
+
+    def region_cigar_batch(self, readpool, opool_bytes, reqs, tasks, task_cigar_words, cig_cap=24, md_cap=64):
+        """One record per region: bwa_gen_cigar2's byte work around ksw_global2 on the device (reference bwa.c:89-172, bwamem.c:1194-1201);
+        needs set_pac().  Returns (results, cigar words [n, cig_cap], MD bytes [n, md_cap])."""
+        readpool = np.ascontiguousarray(readpool, dtype=np.uint8)
+        reqs = np.ascontiguousarray(reqs, dtype=REGION_REQ)
+        tasks = np.ascontiguousarray(tasks, dtype=GLB_TASK)
+        res = np.zeros(len(reqs), dtype=REGION_RES)
+        cig = np.zeros((max(len(reqs), 1), cig_cap), dtype=np.uint32)
+        md = np.zeros((max(len(reqs), 1), md_cap), dtype=np.uint8)
+        self._check(lib().bmh_region_cigar_batch(self._h, _ptr(readpool), readpool.nbytes, int(opool_bytes), _ptr(reqs), len(reqs),
+                                                 _ptr(tasks), len(tasks), int(task_cigar_words), int(cig_cap), int(md_cap), _ptr(res),
+                                                 _ptr(cig), _ptr(md)))
+        return res, cig, md
 
     # ---- L2, device-resident (raw device pointers, e.g. torch tensors' data_ptr())
     def sw_batch(self, pool, tasks):

@@ -243,7 +243,7 @@ int bmh_ctx_destroy(bmh_ctx_t *ctx)
 	if (ctx->stream) (void)stream_wait(ctx, ctx->stream);
 	free_buf(ctx->d_pool), free_buf(ctx->d_tasks), free_buf(ctx->d_res), free_buf(ctx->d_order);
 	free_buf(ctx->d_cigar), free_buf(ctx->d_scratch), free_buf(ctx->d_bins), free_buf(ctx->d_zslab), free_buf(ctx->d_sw), free_buf(ctx->d_swrm);
-	free_buf(ctx->d_seedws);
+	free_buf(ctx->d_seedws), free_buf(ctx->d_region);
 	for (auto &h : ctx->hint) {
 		if (h.ev) (void)hipEventDestroy(h.ev);
 		if (h.h) (void)hipHostFree(h.h);
@@ -783,6 +783,81 @@ int bmh_global_batch(bmh_ctx_t *ctx, const uint8_t *pool, size_t pool_bytes, con
 	rc = fetch_err(ctx);
 	st.finish();
 	return rc;
+}
+
+// ------------------------------------------------------------------ the region record (bwa_gen_cigar2 around ksw_global2)
+
+int bmh_region_cigar_batch(bmh_ctx_t *ctx, const uint8_t *readpool, size_t readpool_bytes, size_t opool_bytes, const bmh_region_req_t *reqs,
+                           int64_t n_req, const bmh_glb_task_t *tasks, int64_t n_tasks, size_t task_cigar_words, int cig_cap, int md_cap,
+                           bmh_region_res_t *results, uint32_t *cigar_out, char *md_out)
+{
+	if (!ctx || n_req < 0 || n_tasks < 0 || cig_cap < 1 || md_cap < 1) return BMH_E_ARG;
+	if (n_req > 0 && (!readpool || !reqs || !results || !cigar_out || !md_out)) return BMH_E_ARG;
+	if (n_tasks > 0 && !tasks) return BMH_E_ARG;
+	if (!ctx->have_params) return BMH_E_ARG;
+	if (!ctx->dev.pac) {
+		ctx->last_error = "bmh_region_cigar_batch needs the resident reference (bmh_ctx_set_pac)";
+		return BMH_E_ARG;
+	}
+	if (n_req == 0) return BMH_OK;
+	if (n_req > 0x7fffffffLL || n_tasks > 0xffffffffLL) return BMH_E_ARG;
+	const int64_t l_pac = ctx->dev.l_pac;
+	for (int64_t k = 0; k < n_req; ++k) { // every byte the kernels will address
+		const bmh_region_req_t &r = reqs[k];
+		bool ok = r.ql >= 1 && r.tl >= 1 && r.ql <= 65535 && r.tl <= 65535 && r.q_src + (uint64_t)r.ql <= readpool_bytes &&
+		          r.o_off + (uint64_t)r.ql + (uint64_t)r.tl <= opool_bytes && r.rb >= 0 && r.rb + r.tl <= l_pac << 1 &&
+		          !(r.rb < l_pac && r.rb + r.tl > l_pac);
+		const int nt = r.truesc == INT32_MIN ? 1 : 3;
+		if (ok && r.task[0] >= 0)
+			for (int t = 0; t < nt; ++t) ok = ok && r.task[t] >= 0 && r.task[t] < n_tasks;
+		if (ok && r.task[0] < 0) ok = r.ql == r.tl;
+		if (!ok) {
+			ctx->last_error = "region " + std::to_string(k) + " is outside its pools, the reference or the task list";
+			return BMH_E_ARG;
+		}
+	}
+	GlbShape gs;
+	int rc;
+	if (n_tasks > 0 && (rc = validate_glb(ctx, tasks, n_tasks, opool_bytes, true, task_cigar_words, &gs))) return rc;
+	GateGuard gate;
+	BMH_HIP(ctx, hipSetDevice(ctx->device));
+	// device pool = [oriented copies | the query windows as uploaded]
+	const size_t rpool_off = (opool_bytes + 16 + 63) & ~(size_t)63;
+	ctx->pool_resident = false;
+	if ((rc = ensure(ctx, ctx->d_pool, rpool_off + readpool_bytes + 16))) return rc;
+	if ((rc = ensure(ctx, ctx->d_tasks, (size_t)std::max<int64_t>(n_tasks, 1) * sizeof(bmh_glb_task_t)))) return rc;
+	if ((rc = ensure(ctx, ctx->d_res, (size_t)std::max<int64_t>(n_tasks, 1) * sizeof(bmh_glb_result_t)))) return rc;
+	if ((rc = ensure(ctx, ctx->d_cigar, (task_cigar_words + 4) * 4))) return rc;
+	const size_t req_b = ((size_t)n_req * sizeof(bmh_region_req_t) + 255) & ~(size_t)255;
+	const size_t res_b = ((size_t)n_req * sizeof(bmh_region_res_t) + 255) & ~(size_t)255;
+	const size_t cig_b = ((size_t)n_req * (size_t)cig_cap * 4 + 255) & ~(size_t)255;
+	const size_t md_b = ((size_t)n_req * (size_t)md_cap + 255) & ~(size_t)255;
+	if ((rc = ensure(ctx, ctx->d_region, req_b + res_b + cig_b + md_b))) return rc;
+	uint8_t *d_reg = (uint8_t *)ctx->d_region.p;
+	bmh_region_req_t *d_reqs = (bmh_region_req_t *)d_reg;
+	bmh_region_res_t *d_rres = (bmh_region_res_t *)(d_reg + req_b);
+	uint32_t *d_cout = (uint32_t *)(d_reg + req_b + res_b);
+	char *d_md = (char *)(d_reg + req_b + res_b + cig_b);
+	Stager st;
+	if ((rc = st.begin(ctx, readpool_bytes + 64 + (size_t)n_req * sizeof(bmh_region_req_t) + 64 + (size_t)n_tasks * sizeof(bmh_glb_task_t) + 64,
+	                   res_b + cig_b + md_b)))
+		return rc;
+	if ((rc = st.h2d((uint8_t *)ctx->d_pool.p + rpool_off, readpool, readpool_bytes))) return rc;
+	if ((rc = st.h2d(d_reqs, reqs, (size_t)n_req * sizeof(bmh_region_req_t)))) return rc;
+	if (n_tasks > 0 && (rc = st.h2d(ctx->d_tasks.p, tasks, (size_t)n_tasks * sizeof(bmh_glb_task_t)))) return rc;
+	if ((rc = launch_region_orient(ctx, (uint8_t *)ctx->d_pool.p, rpool_off, d_reqs, n_req))) return rc;
+	if (n_tasks > 0 && (rc = launch_global(ctx, (const uint8_t *)ctx->d_pool.p, (const bmh_glb_task_t *)ctx->d_tasks.p, n_tasks,
+	                                       (bmh_glb_result_t *)ctx->d_res.p, (uint32_t *)ctx->d_cigar.p, nullptr, gs.qmax, gs.tmax, gs.wmax, gs.wraw)))
+		return rc;
+	if ((rc = launch_region_finish(ctx, (const uint8_t *)ctx->d_pool.p, d_reqs, n_req, (const bmh_glb_task_t *)ctx->d_tasks.p,
+	                               (const bmh_glb_result_t *)ctx->d_res.p, (const uint32_t *)ctx->d_cigar.p, d_rres, d_cout, cig_cap, d_md, md_cap)))
+		return rc;
+	if ((rc = st.d2h(results, d_rres, (size_t)n_req * sizeof(bmh_region_res_t)))) return rc;
+	if ((rc = st.d2h(cigar_out, d_cout, (size_t)n_req * (size_t)cig_cap * 4))) return rc;
+	if ((rc = st.d2h(md_out, d_md, (size_t)n_req * (size_t)md_cap))) return rc;
+	rc = fetch_err(ctx);
+	st.finish();
+	return rc == BMH_E_CIGAR_CAP ? BMH_OK : rc; // a task that outgrew its slots is reported per region (BMH_REGION_CIGAR_CUT)
 }
 
 // ------------------------------------------------------------------ local Smith-Waterman (ksw_align2)

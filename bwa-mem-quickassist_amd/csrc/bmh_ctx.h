@@ -85,6 +85,7 @@ struct bmh_ctx {
 		uint32_t cnt[8] = {};
 	} hint[kHintKinds];
 	DevBuf d_seedws; // workspace of the fused per-seed extension (seedext.hip)
+	DevBuf d_region; // region records, their results, CIGAR and MD slots (bmh_region_cigar_batch)
 	bmh_seedext_stats_t sstats{};
 	int64_t seed_pending_n = -1; // tasks of the bmh_seedext_submit() in flight, -1 = none
 };
@@ -173,5 +174,10 @@ int launch_extend_reg(bmh_ctx *ctx, int ns, const uint8_t *d_pool, const bmh_ext
 int launch_global(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_glb_task_t *d_tasks, int64_t n,
                   bmh_glb_result_t *d_res, uint32_t *d_cigar, const uint32_t *d_order, int qmax, int tmax,
                   int wmax, int wgate);
+
+int launch_region_orient(bmh_ctx *ctx, uint8_t *d_pool, size_t rpool_off, const bmh_region_req_t *d_reqs, int64_t n);
+int launch_region_finish(bmh_ctx *ctx, const uint8_t *d_pool, const bmh_region_req_t *d_reqs, int64_t n, const bmh_glb_task_t *d_tasks,
+                         const bmh_glb_result_t *d_gres, const uint32_t *d_tcig, bmh_region_res_t *d_out, uint32_t *d_cig_out, int cig_cap,
+                         char *d_md_out, int md_cap);
 
 } // namespace bmh

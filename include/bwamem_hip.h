@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BMH_VERSION 300 /* 0.3.0: bmh_smem_opt_t grew min_emit_len (20 bytes), mem_align1_core, *_batch_sharded */
+#define BMH_VERSION 310 /* 0.3.1: bmh_region_cigar_batch (0.3.0: bmh_smem_opt_t grew min_emit_len (20 bytes), mem_align1_core, *_batch_sharded) */
 
 enum {
 	BMH_OK = 0,
@@ -332,6 +332,42 @@ typedef struct bmh_cigar_res {
 int bmh_reg2cigar_batch(bmh_ctx_t *ctx, int64_t l_pac, const uint8_t *pac, const bmh_read_t *reads, int64_t n_req,
                         const bmh_cigar_req_t *reqs, bmh_cigar_res_t *results, uint32_t *cigar_pool,
                         size_t cigar_words, char *md_pool, size_t md_bytes);
+
+/* ---- L2.6: one record per REGION -- everything bwa_gen_cigar2 (bwa.c:89-172) does with sequence bytes, and the replay of mem_reg2aln's
+ * band loop (bwamem.c:1193-1201), on the device, against the 2-bit reference made resident by bmh_ctx_set_pac():
+ *   - bns_get_seq of [rb, rb+tl) on the doubled coordinate and the reversal of query and window for reverse-strand hits (bwa.c:100-107):
+ *     the oriented copies are written into a device pool, query k at o_off, its window right behind it at o_off + ql;
+ *   - the no-gap shortcut's score, sum of mat[t*5+q] (bwa.c:108-114), for a region whose task[0] is -1;
+ *   - ksw_global2 + traceback of `tasks` (their q_off / t_off address that oriented pool; cigar_off / cigar_cap a device-side scratch
+ *     of `task_cigar_words` words);
+ *   - per region the loop over its tries task[0..2]: stop when the score repeats or reaches truesc - a, or after one try when
+ *     truesc == INT32_MIN (bwamem.c:1194-1201; equal bands share a task index);
+ *   - NM and MD of the final try (bwa.c:134-164), MD with "ACGTN" or, on the reverse strand, "TGCAN".
+ * The host keeps what needs no sequence: band inference and the band of each try (bwamem.c:884-891,1187-1191, bwa.c:116-125).
+ * Returned per region: the record below, its CIGAR words at cigar_out[k*cig_cap ..] and its MD bytes (no NUL) at md_out[k*md_cap ..].
+ * A CIGAR longer than the final task's cigar_cap or cig_cap, or an MD longer than md_cap, is flagged and not returned (the caller
+ * redoes those few regions with full capacities, e.g. through bmh_global_batch); score, n_cigar and tries are exact either way. */
+#define BMH_REGION_CIGAR_CUT 1u /* n_cigar exceeds the capacity: CIGAR, NM and MD not returned */
+#define BMH_REGION_MD_CUT 2u    /* MD longer than md_cap: NM is exact, the MD bytes are not returned */
+typedef struct bmh_region_req { /* 48 bytes */
+	uint64_t q_src;  /* offset in readpool of query base qb, read orientation, one base code per byte */
+	int64_t rb;      /* doubled coordinate of the window's first base; [rb, rb+tl) must not bridge l_pac (bwa.c:99) */
+	uint64_t o_off;  /* where the oriented query goes in the device pool (the window follows at o_off + ql) */
+	int32_t ql, tl;
+	int32_t truesc;  /* INT32_MIN: one try */
+	int32_t task[3]; /* index into tasks[] of try 0..2; -1 = no such try; task[0] == -1: the no-gap case */
+} bmh_region_req_t;
+typedef struct bmh_region_res { /* 24 bytes */
+	int32_t score, n_cigar, tries, NM;
+	int32_t md_len;
+	uint32_t flags; /* BMH_REGION_* */
+} bmh_region_res_t;
+/* readpool: the query windows; opool_bytes: size of the oriented pool the o_off / q_off / t_off fields address.  BMH_E_ARG without a
+ * resident reference or with offsets outside the pools. */
+int bmh_region_cigar_batch(bmh_ctx_t *ctx, const uint8_t *readpool, size_t readpool_bytes, size_t opool_bytes,
+                           const bmh_region_req_t *reqs, int64_t n_req, const bmh_glb_task_t *tasks, int64_t n_tasks,
+                           size_t task_cigar_words, int cig_cap, int md_cap, bmh_region_res_t *results, uint32_t *cigar_out,
+                           char *md_out);
 
 /* Counters of the last bmh_chain2aln_batch call (for the bench / logs). */
 typedef struct bmh_driver_stats {

@@ -40,6 +40,7 @@ def test_record_layouts_match_header(pkg):
     assert "bmh_ext_task_t" in hdr and "bmh_glb_task_t" in hdr
     assert pkg.EXT_TASK.itemsize == 32 and pkg.EXT_RES.itemsize == 24
     assert pkg.GLB_TASK.itemsize == 32 and pkg.GLB_RES.itemsize == 8
+    assert pkg.REGION_REQ.itemsize == 48 and pkg.REGION_RES.itemsize == 24
     assert pkg.PARAMS.itemsize == 64 and pkg.ALNREG.itemsize == 64 and pkg.SEED.itemsize == 16
     for a, b in ((pkg.EXT_TASK, kswlib.EXT_TASK), (pkg.EXT_RES, kswlib.EXT_RES), (pkg.GLB_TASK, kswlib.GLB_TASK)):
         assert a == b
@@ -47,7 +48,7 @@ def test_record_layouts_match_header(pkg):
 
 def test_version_and_strerror(pkg):
     lib = pkg.lib()
-    assert lib.bmh_version() == 300
+    assert lib.bmh_version() == 310
     assert lib.bmh_strerror(0) == b"ok"
     assert b"range" in lib.bmh_strerror(pkg.BMH_E_RANGE)
 

@@ -59,12 +59,16 @@ def test_hip_chain2aln_driver_matches_reference_fixture(ctx):
     assert nreg >= 2500
 
 
-def test_hip_reg2cigar_driver_matches_reference_fixture(ctx):
+@pytest.mark.parametrize("path", ["host copies", "region records"])
+def test_hip_reg2cigar_driver_matches_reference_fixture(ctx, path):
     """bmh_reg2cigar_batch (batched GPU rounds) == the reference's mem_reg2aln (CIGAR, NM, MD), and == the oracle
-    on score and number of tries."""
+    on score and number of tries.  "region records": with the 2-bit reference resident on the device the driver hands window fetch,
+    orientation, the no-gap score, the replay of the band loop, NM and MD to bmh_region_cigar_batch."""
     n = 0
     for p, l_pac, pac, reads, reqs, exp in kswlib.golden_cigar_groups():
         ctx.set_params(p)
+        if path == "region records":
+            pac = ctx.set_pac(pac, l_pac)
         res, cig, md = ctx.reg2cigar_batch(l_pac, pac, reads, reqs)
         mdb = bytes(md)
         for rq, r, (en, ew, enm, emd) in zip(reqs, res, exp):
@@ -81,9 +85,11 @@ def test_hip_reg2cigar_driver_matches_reference_fixture(ctx):
     assert n >= 2000
 
 
-def test_hip_reg2cigar_long_cigars_take_the_retry_path(ctx):
+@pytest.mark.parametrize("path", ["host copies", "region records"])
+def test_hip_reg2cigar_long_cigars_take_the_retry_path(ctx, path):
     """The driver reserves few CIGAR slots per task and redoes a task whose CIGAR needs more: reads with an indel every
-    ~25 bases (50+ operations), both strands, mixed with ordinary ones, against the oracle."""
+    ~25 bases (50+ operations), both strands, mixed with ordinary ones, against the oracle.  With region records the long ones (and
+    those whose MD outgrows its slot) come back flagged and are redone through the path with host copies."""
     rng = np.random.default_rng(201)
     l_pac = 20000
     bases = rng.integers(0, 4, l_pac, dtype=np.uint8)
@@ -119,6 +125,8 @@ def test_hip_reg2cigar_long_cigars_take_the_retry_path(ctx):
         rq["read"], rq["qb"], rq["qe"], rq["rb"], rq["re"], rq["truesc"], rq["reg_w"] = len(reads), 0, len(rd), rb, re, len(rd) - 60, 100
         reads.append(rd), reqs.append(rq)
     reqs = np.array(reqs)
+    if path == "region records":
+        pac = ctx.set_pac(pac, l_pac)
     res, cig, md = ctx.reg2cigar_batch(l_pac, pac, reads, reqs)
     mdb = bytes(md)
     long_ones = 0

@@ -114,3 +114,156 @@ def test_chain2aln_driver_with_resident_reference_matches_reference_fixture():
         assert st["pool_bytes"] == sum(len(x) for x in reads) + 16, "windows must not be shipped"
     assert nreg >= 2500
     ctx.close()
+
+
+# ---- the region record: bwa_gen_cigar2's byte work on the device (bmh_region_cigar_batch) ---------------------------------------
+
+def _md_of(words, q, t, rev):
+    """bwa.c:134-164 on oriented copies"""
+    b2c = b"TGCAN" if rev else b"ACGTN"
+    x = y = u = mm = gap = 0
+    out = bytearray()
+    for k, wd in enumerate(words):
+        op, ln = int(wd) & 0xf, int(wd) >> 4
+        if op == 0:
+            for i in range(ln):
+                if q[x + i] != t[y + i]:
+                    out += str(u).encode() + b2c[t[y + i]:t[y + i] + 1]
+                    mm, u = mm + 1, 0
+                else:
+                    u += 1
+            x, y = x + ln, y + ln
+        elif op == 2:
+            if 0 < k < len(words) - 1:
+                out += str(u).encode() + b"^" + bytes(b2c[c] for c in t[y:y + ln])
+                u, gap = 0, gap + ln
+            y += ln
+        elif op == 1:
+            x, gap = x + ln, gap + ln
+    out += str(u).encode()
+    return mm + gap, bytes(out)
+
+
+def test_region_records_against_oracle_global_and_md():
+    """bmh_region_cigar_batch record by record: windows of both strands fetched and oriented on the device, three tries per region with
+    bands given here, one-try regions, no-gap regions; against the oracle's ksw_global2 on oriented copies made in numpy, the band loop
+    replayed in Python and a Python restatement of bwa.c:134-164.  Then the capacity flags, and the loud error without a reference."""
+    from __graft_entry__ import load_package
+    pkg = load_package()
+    rng = np.random.default_rng(611)
+    l_pac = 60000
+    bases = rng.integers(0, 4, l_pac, dtype=np.uint8)
+    pad = np.concatenate([bases, np.zeros((-l_pac) % 4 + 4, np.uint8)])
+    q4 = pad[: (len(pad) // 4) * 4].reshape(-1, 4)
+    pac = (q4[:, 0] << 6 | q4[:, 1] << 4 | q4[:, 2] << 2 | q4[:, 3]).astype(np.uint8)
+    dbl = np.concatenate([bases, (3 - bases)[::-1]])
+    p = kswlib.make_params()
+    ctx = _ctx_with({})
+    try:
+        ctx.set_params(p)
+        reqs, tasks, rpool, opool = [], [], [], []
+        rb_, ob_, slot = 0, 0, 0
+        INT_MIN = -2 ** 31
+        for k in range(400):
+            L = int(rng.integers(30, 260))
+            rev = k & 1
+            lo, hi = (l_pac, 2 * l_pac) if rev else (0, l_pac)
+            pos = int(rng.integers(lo + 10, hi - L - 40))
+            tl = L
+            read = dbl[pos:pos + L].copy()
+            kind = k % 4
+            if kind != 3:  # mismatches, and for kinds 1-2 an indel
+                mut = rng.random(L) < 0.05
+                read[mut] = (read[mut] + rng.integers(1, 4, mut.sum())) & 3
+            if kind in (1, 2) and L > 40:
+                c = int(rng.integers(10, L - 10))
+                d = int(rng.integers(1, 6))
+                if kind == 1:
+                    read = np.concatenate([read[:c], read[c + d:]])          # deletion from the read
+                else:
+                    read = np.concatenate([read[:c], rng.integers(0, 4, d).astype(np.uint8), read[c:]])  # insertion
+            if k % 17 == 0:
+                read[int(rng.integers(0, len(read)))] = 4  # an N
+            ql = len(read)
+            q = np.zeros((), pkg.REGION_REQ)
+            q["q_src"], q["rb"], q["o_off"], q["ql"], q["tl"] = rb_, pos, ob_, ql, tl
+            single = k % 5 == 0
+            q["truesc"] = INT_MIN if single else ql - int(rng.integers(0, 30))
+            oq = read[::-1] if rev else read
+            ot = dbl[pos:pos + tl][::-1] if rev else dbl[pos:pos + tl]
+            task = [-1, -1, -1]
+            if not (kind in (0, 3) and k % 8 < 4):  # (mismatch-only regions: half of them as the no-gap case)
+                prev = -1
+                for t_ in range(1 if single else 3):
+                    w = max(abs(tl - ql) + 3, (2 + k % 7) << t_)
+                    w = min(w, 40)
+                    if w == prev:
+                        task[t_] = task[t_ - 1]
+                        continue
+                    prev = w
+                    g = np.zeros((), pkg.GLB_TASK)
+                    g["q_off"], g["t_off"], g["qlen"], g["tlen"], g["w"], g["cigar_off"], g["cigar_cap"] = ob_, ob_ + ql, ql, tl, w, slot, 24
+                    slot += 24
+                    task[t_] = len(tasks)
+                    tasks.append(g)
+            q["task"] = task
+            reqs.append(q), rpool.append(read)
+            opool += [oq, ot]
+            rb_ += ql
+            ob_ += ql + tl
+        reqs, tasks = np.array(reqs), np.array(tasks)
+        rpool, opool = np.concatenate(rpool), np.concatenate(opool)
+        with pytest.raises(pkg.BmhError):  # no resident reference yet
+            ctx.region_cigar_batch(rpool, len(opool), reqs, tasks, slot + 4)
+        ctx.set_pac(pac, l_pac)
+        res, cig, md = ctx.region_cigar_batch(rpool, len(opool), reqs, tasks, slot + 4)
+        ores, ocig = kswlib.orc_global_batch(p, opool, tasks) if len(tasks) else (None, None)
+        a = int(p["a"])
+        mat = np.array(p["mat"], dtype=np.int64).reshape(5, 5)
+        seen = {"nodp": 0, "tries2": 0, "rev_indel": 0}
+        for k, (q, r) in enumerate(zip(reqs, res)):
+            ql, tl, rev = int(q["ql"]), int(q["tl"]), int(q["rb"]) >= l_pac
+            oq = opool[int(q["o_off"]):int(q["o_off"]) + ql]
+            ot = opool[int(q["o_off"]) + ql:int(q["o_off"]) + ql + tl]
+            single = int(q["truesc"]) == INT_MIN
+            if q["task"][0] < 0:
+                sc = int(mat[ot, oq].sum())
+                words, tries = np.array([ql << 4], dtype=np.uint32), (2 if (not single and sc < int(q["truesc"]) - a) else 1)
+                seen["nodp"] += 1
+            else:
+                last, tries = -(1 << 30), 0
+                for t_ in range(3):
+                    fin = int(q["task"][t_])
+                    tries += 1
+                    sc = int(ores[fin]["score"])
+                    if sc == last:
+                        break
+                    last = sc
+                    if single or not (tries < 3 and sc < int(q["truesc"]) - a):
+                        break
+                n = int(ores[fin]["n_cigar"])
+                assert n <= 24
+                words = ocig[fin]
+                seen["tries2"] += tries >= 2
+                seen["rev_indel"] += rev and n > 1
+            nm, mds = _md_of(words, oq, ot, rev)
+            assert (int(r["score"]), int(r["n_cigar"]), int(r["tries"])) == (sc, len(words), tries), (k, q, r)
+            assert int(r["flags"]) == 0 and int(r["NM"]) == nm and int(r["md_len"]) == len(mds), (k, q, r, mds)
+            assert np.array_equal(cig[k, :len(words)], words) and bytes(md[k, :len(mds)]) == mds
+        assert min(seen.values()) >= 10, seen
+        # capacities: 2 CIGAR words / 6 MD bytes per region -- what does not fit is flagged, the rest is as before
+        res2, cig2, md2 = ctx.region_cigar_batch(rpool, len(opool), reqs, tasks, slot + 4, cig_cap=2, md_cap=6)
+        cut = {1: 0, 2: 0, 0: 0}
+        for k, (r, r2) in enumerate(zip(res, res2)):
+            assert (int(r2["score"]), int(r2["n_cigar"]), int(r2["tries"])) == (int(r["score"]), int(r["n_cigar"]), int(r["tries"]))
+            if int(r["n_cigar"]) > 2:
+                assert int(r2["flags"]) == pkg.BMH_REGION_CIGAR_CUT
+            else:
+                assert int(r2["NM"]) == int(r["NM"]) and int(r2["md_len"]) == int(r["md_len"])
+                assert int(r2["flags"]) == (pkg.BMH_REGION_MD_CUT if int(r["md_len"]) > 6 else 0)
+                if not r2["flags"]:
+                    assert bytes(md2[k, :int(r2["md_len"])]) == bytes(md[k, :int(r["md_len"])])
+            cut[int(r2["flags"])] += 1
+        assert min(cut.values()) >= 10, cut
+    finally:
+        ctx.close()
