@@ -482,6 +482,81 @@ __global__ void sa_of_intervals_kernel(DevBwt B, const Intv *__restrict__ intv, 
 	}
 }
 
+// ---- per-read order on the device.  The SMEM kernels append calls and intervals in completion order; what the caller gets is every
+// read's calls in call order with their intervals behind one another (the order smem_next2 / mem_chain walk them in, bwamem.c:118-162,
+// 208-243).  Putting them back was a pass over the downloaded arrays on the host -- 4 ms per 33 k-read batch, inside the device gate, a
+// fifth of a seeding batch's wall time in the pipeline.  Four small kernels do it behind the SMEM kernel instead: count per read, one
+// block's scan, place the calls (their sequence number within the read is in .rsv), then one lane per read lays out its intervals.
+__global__ void smem_order_count(const bmh_smem_call_t *__restrict__ calls, const uint32_t *__restrict__ cread,
+                                 const unsigned long long *__restrict__ cursors, unsigned long long call_cap, unsigned long long intv_cap,
+                                 uint32_t *__restrict__ ccnt, uint32_t *__restrict__ icnt)
+{
+	if (cursors[0] > call_cap || cursors[1] > intv_cap) return; // overflowed attempt
+	const unsigned long long n = cursors[0];
+	for (unsigned long long c = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (unsigned long long)gridDim.x * blockDim.x) {
+		const uint32_t r = cread[c];
+		atomicAdd(&ccnt[r], 1u);
+		if (calls[c].n) atomicAdd(&icnt[r], (uint32_t)calls[c].n);
+	}
+}
+
+// exclusive sums of both count arrays, n + 1 outputs each (the last one is the total); one block of 1024 threads
+__global__ __launch_bounds__(1024) void smem_order_scan(const uint32_t *__restrict__ ccnt, const uint32_t *__restrict__ icnt, int n,
+                                                        uint32_t *__restrict__ coff, uint64_t *__restrict__ ioff)
+{
+	__shared__ unsigned long long pc[1024], pi[1024];
+	const int t = threadIdx.x, per = (n + 1023) / 1024, lo = min(t * per, n), hi = min(lo + per, n);
+	unsigned long long sc = 0, si = 0;
+	for (int k = lo; k < hi; ++k) sc += ccnt[k], si += icnt[k];
+	pc[t] = sc, pi[t] = si;
+	__syncthreads();
+	for (int d = 1; d < 1024; d <<= 1) { // inclusive scan of the 1024 partial sums
+		const unsigned long long ac = t >= d ? pc[t - d] : 0, ai = t >= d ? pi[t - d] : 0;
+		__syncthreads();
+		pc[t] += ac, pi[t] += ai;
+		__syncthreads();
+	}
+	unsigned long long bc = pc[t] - sc, bi = pi[t] - si;
+	for (int k = lo; k < hi; ++k) {
+		coff[k] = (uint32_t)bc, ioff[k] = bi;
+		bc += ccnt[k], bi += icnt[k];
+	}
+	if (t == 1023) coff[n] = (uint32_t)pc[1023], ioff[n] = pi[1023];
+}
+
+__global__ void smem_order_place(const bmh_smem_call_t *__restrict__ calls, const uint32_t *__restrict__ cread,
+                                 const unsigned long long *__restrict__ cursors, unsigned long long call_cap, unsigned long long intv_cap,
+                                 const uint32_t *__restrict__ coff, bmh_smem_call_t *__restrict__ calls2)
+{
+	if (cursors[0] > call_cap || cursors[1] > intv_cap) return;
+	const unsigned long long n = cursors[0];
+	for (unsigned long long c = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (unsigned long long)gridDim.x * blockDim.x) {
+		const bmh_smem_call_t cl = calls[c];
+		calls2[coff[cread[c]] + cl.rsv] = cl; // .rsv = the call's sequence number within its read
+	}
+}
+
+__global__ void smem_order_intervals(int n_reads, const uint32_t *__restrict__ coff, bmh_smem_call_t *__restrict__ calls2,
+                                     const uint64_t *__restrict__ ioff, const Intv *__restrict__ intv, Intv *__restrict__ intv2,
+                                     const uint64_t *__restrict__ pb, uint64_t *__restrict__ pb2, const unsigned long long *__restrict__ cursors,
+                                     unsigned long long call_cap, unsigned long long intv_cap)
+{
+	if (cursors[0] > call_cap || cursors[1] > intv_cap) return;
+	const int r = blockIdx.x * blockDim.x + threadIdx.x;
+	if (r >= n_reads) return;
+	uint32_t local = 0;
+	const uint64_t base = ioff[r];
+	for (uint32_t c = coff[r]; c < coff[r + 1]; ++c) {
+		bmh_smem_call_t cl = calls2[c];
+		for (int k = 0; k < cl.n; ++k) {
+			intv2[base + local + k] = intv[cl.first + k];
+			if (pb) pb2[base + local + k] = pb[cl.first + k];
+		}
+		cl.first = local, cl.rsv = 0, local += (uint32_t)cl.n;
+		calls2[c] = cl;
+	}
+}
+
 // ---- host side: one resident copy of the index per (device, host arrays), shared by all contexts ----
 struct BwtShare {
 	int device;
@@ -632,6 +707,8 @@ static int smem_impl(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const
 	if (const char *e = getenv("BMH_SMEM_LANES")) lanes = atoi(e) >= 8 && atoi(e) <= 64 ? atoi(e) : 64; // (A/B knob; fewer measured slower)
 	// 105 VGPRs -> 4 waves per SIMD; the 94-register build fits 5: worth it once the batch has more waves than 4 per SIMD
 	// (500 k reads: 20.4 -> 18.9 ms), not below (200 k: 10.0 -> 10.3 ms)
+	static const bool host_order = getenv("BMH_SMEM_HOST_ORDER") && atoi(getenv("BMH_SMEM_HOST_ORDER")) != 0; // (A/B: the per-read order made on the host)
+	const bool dev_order = !host_order;
 	int emit_min = 16;
 	if (const char *e = getenv("BMH_SMEM_EMIT")) emit_min = atoi(e) >= 1 && atoi(e) <= 64 ? atoi(e) : 16; // (tuning knob)
 	// Two kernels, same results.  smem_conv_kernel (one extension site, 46 % of the VALU lanes active against 25 %, but about
@@ -664,7 +741,11 @@ static int smem_impl(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const
 		const size_t hdr = 64, o_pool = hdr, o_off = o_pool + ((bytes + 16 + 63) & ~(size_t)63), o_len = o_off + (size_t)n_reads * 8,
 		             o_calls = (o_len + (size_t)n_reads * 4 + 63) & ~(size_t)63, o_cr = o_calls + d_calls * sizeof(bmh_smem_call_t),
 		             o_intv = (o_cr + d_calls * 4 + 63) & ~(size_t)63, o_pb = o_intv + d_intv * sizeof(Intv), o_pos = o_pb + (sp ? d_intv * 8 : 0),
-		             total = o_pos + d_pos * 8;
+		             // ... and the same in per-read order (smem_order_*): counts, offsets, calls, intervals, position bases
+		             nr1 = ((size_t)n_reads + 1 + 15) & ~(size_t)15, o_ccnt = (o_pos + d_pos * 8 + 63) & ~(size_t)63, o_icnt = o_ccnt + nr1 * 4,
+		             o_coff = o_icnt + nr1 * 4, o_ioff = o_coff + nr1 * 4, o_calls2 = o_ioff + nr1 * 8,
+		             o_intv2 = (o_calls2 + d_calls * sizeof(bmh_smem_call_t) + 63) & ~(size_t)63, o_pb2 = o_intv2 + d_intv * sizeof(Intv),
+		             total = o_pb2 + (sp ? d_intv * 8 : 0);
 		if ((rc = ensure(ctx, ctx->d_scratch, total))) return rc;
 		if ((rc = ensure(ctx, ctx->d_sw, (size_t)grid * 3 * (size_t)lcap * 64 * sizeof(Intv)))) return rc;
 		uint8_t *d = (uint8_t *)ctx->d_scratch.p;
@@ -696,6 +777,23 @@ static int smem_impl(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const
 			                   (unsigned long long *)(d + 32), (int *)(d + 16));
 			BMH_HIP(ctx, hipGetLastError());
 		}
+		if (dev_order) {
+			const unsigned cb = (unsigned)std::min<size_t>((d_calls + 255) / 256, 2048);
+			BMH_HIP(ctx, hipMemsetAsync(d + o_ccnt, 0, nr1 * 8, ctx->stream)); // both count arrays
+			hipLaunchKernelGGL(smem_order_count, dim3(cb), dim3(256), 0, ctx->stream, (const bmh_smem_call_t *)(d + o_calls), (const uint32_t *)(d + o_cr),
+			                   (const unsigned long long *)d, (unsigned long long)d_calls, (unsigned long long)d_intv, (uint32_t *)(d + o_ccnt),
+			                   (uint32_t *)(d + o_icnt));
+			hipLaunchKernelGGL(smem_order_scan, dim3(1), dim3(1024), 0, ctx->stream, (const uint32_t *)(d + o_ccnt), (const uint32_t *)(d + o_icnt), n_reads,
+			                   (uint32_t *)(d + o_coff), (uint64_t *)(d + o_ioff));
+			hipLaunchKernelGGL(smem_order_place, dim3(cb), dim3(256), 0, ctx->stream, (const bmh_smem_call_t *)(d + o_calls), (const uint32_t *)(d + o_cr),
+			                   (const unsigned long long *)d, (unsigned long long)d_calls, (unsigned long long)d_intv, (const uint32_t *)(d + o_coff),
+			                   (bmh_smem_call_t *)(d + o_calls2));
+			hipLaunchKernelGGL(smem_order_intervals, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, ctx->stream, n_reads, (const uint32_t *)(d + o_coff),
+			                   (bmh_smem_call_t *)(d + o_calls2), (const uint64_t *)(d + o_ioff), (const Intv *)(d + o_intv), (Intv *)(d + o_intv2),
+			                   sp ? (const uint64_t *)(d + o_pb) : nullptr, (uint64_t *)(d + o_pb2), (const unsigned long long *)d,
+			                   (unsigned long long)d_calls, (unsigned long long)d_intv);
+			BMH_HIP(ctx, hipGetLastError());
+		}
 		if (ctx->timing) {
 			BMH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
 			ctx->ev_valid = true;
@@ -709,6 +807,34 @@ static int smem_impl(bmh_ctx_t *ctx, const bmh_smem_opt_t *o, int n_reads, const
 		tt[2] = now();
 		if (totals[0] <= d_calls && totals[1] <= d_intv && (!sp || totals[4] <= d_pos)) {
 			n_calls = (size_t)totals[0];
+			if (dev_order) { // everything is in its final order: offsets, calls, intervals, position bases, positions
+				if (totals[0] > call_cap || totals[1] > intv_cap || (totals[0] && (!calls || (!intv && totals[1]))) || (sp && totals[4] > sp->sa_cap)) break;
+				const size_t b_coff = (((size_t)n_reads + 1) * 4 + 63) & ~(size_t)63, b_ioff = ((size_t)n_reads + 1) * 8;
+				const size_t b_c2 = (n_calls * sizeof(bmh_smem_call_t) + 63) & ~(size_t)63, b_i2 = (size_t)totals[1] * sizeof(Intv);
+				const size_t b_p2 = sp ? (size_t)totals[1] * 8 : 0, b_ps = sp ? (size_t)totals[4] * 8 : 0;
+				if ((rc = ensure_host(ctx, ctx->h_down, b_coff + b_ioff + b_c2 + b_i2 + b_p2 + b_ps + 64))) return rc;
+				uint8_t *h = (uint8_t *)ctx->h_down.p;
+				BMH_HIP(ctx, hipMemcpyAsync(h, d + o_coff, ((size_t)n_reads + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+				BMH_HIP(ctx, hipMemcpyAsync(h + b_coff, d + o_ioff, b_ioff, hipMemcpyDeviceToHost, ctx->stream));
+				if (n_calls) BMH_HIP(ctx, hipMemcpyAsync(h + b_coff + b_ioff, d + o_calls2, n_calls * sizeof(bmh_smem_call_t), hipMemcpyDeviceToHost, ctx->stream));
+				if (b_i2) BMH_HIP(ctx, hipMemcpyAsync(h + b_coff + b_ioff + b_c2, d + o_intv2, b_i2, hipMemcpyDeviceToHost, ctx->stream));
+				if (b_p2) BMH_HIP(ctx, hipMemcpyAsync(h + b_coff + b_ioff + b_c2 + b_i2, d + o_pb2, b_p2, hipMemcpyDeviceToHost, ctx->stream));
+				if (b_ps) BMH_HIP(ctx, hipMemcpyAsync(h + b_coff + b_ioff + b_c2 + b_i2 + b_p2, d + o_pos, b_ps, hipMemcpyDeviceToHost, ctx->stream));
+				BMH_HIP(ctx, stream_wait(ctx, ctx->stream));
+				tt[3] = now();
+				memcpy(call_off, h, ((size_t)n_reads + 1) * 4);
+				memcpy(intv_off, h + b_coff, b_ioff);
+				if (n_calls) memcpy(calls, h + b_coff + b_ioff, n_calls * sizeof(bmh_smem_call_t));
+				if (b_i2) memcpy(intv, h + b_coff + b_ioff + b_c2, b_i2);
+				if (b_p2) memcpy(sp->sa_off, h + b_coff + b_ioff + b_c2 + b_i2, b_p2);
+				if (b_ps) memcpy(sp->sa_pos, h + b_coff + b_ioff + b_c2 + b_i2 + b_p2, b_ps);
+				if (sp) sp->n_pos = totals[4];
+				tt[4] = now();
+				if (trace)
+					fprintf(stderr, "[bwamem_hip] bmh_smem_batch %d reads: prepare %.1f ms, upload+kernel %.1f ms, download %.1f ms, reorder %.1f ms\n", n_reads,
+					        (tt[1] - tt[0]) * 1e3, (tt[2] - tt[1]) * 1e3, (tt[3] - tt[2]) * 1e3, (tt[4] - tt[3]) * 1e3);
+				return BMH_OK;
+			}
 			const size_t b_calls = n_calls * sizeof(bmh_smem_call_t), b_read = (n_calls * 4 + 63) & ~(size_t)63, b_intv = (size_t)totals[1] * sizeof(Intv);
 			const size_t b_pb = sp ? (size_t)totals[1] * 8 : 0, b_pos = sp ? (size_t)totals[4] * 8 : 0;
 			if ((rc = ensure_host(ctx, ctx->h_down, b_calls + b_read + b_intv + b_pb + b_pos + 64))) return rc;
