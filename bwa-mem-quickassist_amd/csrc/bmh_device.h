@@ -144,6 +144,12 @@ __device__ __forceinline__ void max16_into_hi(int &r, int a, int b)
 	asm("v_max_i16_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0" : "+v"(r) : "v"(a), "v"(b));
 }
 
+// high half of r = a - b (16-bit), low half kept: two differences whose sign bits are wanted share a register
+__device__ __forceinline__ void sub16_into_hi(int &r, int a, int b)
+{
+	asm("v_sub_u16_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_0" : "+v"(r) : "v"(a), "v"(b));
+}
+
 // ksw.c:401-405 without floating point: trunc((x)/e + 1) floored at 1 equals x/e+1 for x>=0, else 1 (e>=1)
 __device__ __forceinline__ int band_cap(int qlen, int mx, int end_bonus, int o, int e)
 {

@@ -176,8 +176,8 @@ __global__ __launch_bounds__(64, (C <= 64 ? BMH_GL_WAVES64 : C <= 96 ? BMH_GL_WA
 				// Direction state, 4 bits per cell, as the SIGN BITS of four differences (ksw.c:547-561):
 				//   b1 = [m < e]  b2 = [max(m,e) < f]            -> d = b2 ? 2 : b1
 				//   b3 = [e - e_del > m - oe_del] (E continues)    b4 = [f - e_ins > m - oe_ins] (F continues)
-				// b1..b4 of cell c end up in bit c of bytes 0..3 of the block's dword: two shift registers (dz12, dz34; fresh per block) take one
-				// bit per cell at the top of each of their two bytes and move down one place per cell.
+				// bit c of the four bytes of the block's dword = b1, b3, b2, b4 of cell c: two shift registers (dz12, dz34; fresh per block) take
+				// two sign bits per cell at bits 15 and 31 and move down one place per cell.
 				int dz12 = 0, dz34 = 0;
 				auto cells = [&](auto MASKED) {
 #pragma unroll
@@ -191,16 +191,23 @@ __global__ __launch_bounds__(64, (C <= 64 ? BMH_GL_WAVES64 : C <= 96 ? BMH_GL_WA
 							const int e = (int)((unsigned)R[s + 1] >> 16);  // E(i,j)
 							const int h1 = max16(m, e);                     // ksw.c:547-550
 							const int h = max16(h1, f);
-							const int x1 = sub16(m, e), x2 = sub16(h1, f);
 							const int t1 = subk16(m, oe_del), e2 = subk16(e, e_del); // ksw.c:552-556
-							const int x3 = sub16(t1, e2);
 							const int t2 = oe_ins == oe_del ? t1 : subk16(m, oe_ins), f2 = subk16(f, e_ins); // ksw.c:557-560
-							const int x4 = sub16(t2, f2);
-							// the high bytes of two differences side by side (one v_perm), their sign bits into bit 7 of byte 0 and of byte 1
+#ifdef BMH_GL_PERM_SIGNS // (round 3's first form: four differences, their high bytes gathered pairwise by v_perm)
+							const int x1 = sub16(m, e), x2 = sub16(h1, f), x3 = sub16(t1, e2), x4 = sub16(t2, f2);
 							const int z12 = (int)__builtin_amdgcn_perm((unsigned)x1, (unsigned)x2, 0x0c0c0105u);
 							const int z34 = (int)__builtin_amdgcn_perm((unsigned)x3, (unsigned)x4, 0x0c0c0105u);
 							dz12 = __builtin_amdgcn_bitop3_b32((int)((unsigned)dz12 >> 1), z12, 0x8080, 0xf8); // a | (b & c)
 							dz34 = __builtin_amdgcn_bitop3_b32((int)((unsigned)dz34 >> 1), z34, 0x8080, 0xf8);
+#else
+							// two differences per register: the second one is subtracted straight into the high half (SDWA), so that one shift and
+							// one v_bitop3 take both sign bits -- bits 15 and 31 -- into the shift register
+							int x12 = sub16(m, e), x34 = sub16(t1, e2);
+							sub16_into_hi(x12, h1, f);
+							sub16_into_hi(x34, t2, f2);
+							dz12 = __builtin_amdgcn_bitop3_b32((int)((unsigned)dz12 >> 1), x12, (int)0x80008000u, 0xf8); // a | (b & c)
+							dz34 = __builtin_amdgcn_bitop3_b32((int)((unsigned)dz34 >> 1), x34, (int)0x80008000u, 0xf8);
+#endif
 							// register s <- {H(i,j) for the next row's diagonal, E(i+1,j) for the next row's slot s-1}
 							if constexpr (decltype(MASKED)::value) {
 								const int actv = (am[s / 32] << (31 - s % 32)) >> 31;
@@ -223,7 +230,11 @@ __global__ __launch_bounds__(64, (C <= 64 ? BMH_GL_WAVES64 : C <= 96 ? BMH_GL_WA
 				};
 				if (masked) cells(std::true_type{});
 				else if constexpr (FAST) cells(std::false_type{});
-				const uint32_t dz = (uint32_t)dz12 | (uint32_t)dz34 << 16;
+#ifdef BMH_GL_PERM_SIGNS
+				const uint32_t dz = (uint32_t)dz12 | (uint32_t)dz34 << 16; // bytes: b1 b2 b3 b4
+#else
+				const uint32_t dz = (uint32_t)dz12 >> 8 | (uint32_t)dz34; // eight cells on, b1 / b2 stand in bytes 1 / 3 of dz12, b3 / b4 of dz34: bytes b1 b3 b2 b4
+#endif
 				if (want) { // ksw.c:561, eight cells at once: wave-uniform line address in SGPRs + the lane's byte offset
 					const uint32_t *line = zbase + ((size_t)b * (size_t)rows_cap + (size_t)i) * 64;
 					asm volatile("global_store_dword %0, %1, %2" : : "v"(lane * 4), "v"(dz), "s"(line) : "memory");
@@ -294,8 +305,12 @@ __global__ __launch_bounds__(64, (C <= 64 ? BMH_GL_WAVES64 : C <= 96 ? BMH_GL_WA
 				}
 				if (act) {
 					const uint32_t dzw = strip[(ctop - ti) * 64 + lane] >> (s & 7);
-					// bit 0 = [m < e], bit 8 = [max(m,e) < f], bit 16 = E continues, bit 24 = F continues (see the fill)
+					// bit 0 = [m < e], bit 16 = [max(m,e) < f], bit 8 = E continues, bit 24 = F continues (see the fill)
+#ifdef BMH_GL_PERM_SIGNS
 					which = which == 0 ? ((dzw >> 8 & 1) ? 2 : (int)(dzw & 1)) : which == 1 ? (int)(dzw >> 16 & 1) : (int)(dzw >> 23 & 2);
+#else
+					which = which == 0 ? ((dzw >> 16 & 1) ? 2 : (int)(dzw & 1)) : which == 1 ? (int)(dzw >> 8 & 1) : (int)(dzw >> 23 & 2);
+#endif
 					const int op = which == 0 ? 0 : (which == 1 ? 2 : 1);
 					if (last_len > 0 && op == last_op) ++last_len; // ksw.c:489-499
 					else {
