@@ -696,7 +696,7 @@ def main():
             if ext_bin_ms[b] > 0:
                 kernels.append({"kernel": ext_names[b], "ms": float(ext_bin_ms[b]), "launches": max(1, ext_bin_launches), "single_kernel": b < 2,
                                 "algorithmic_bytes": ext_bytes * ext_bin_ms[b] / ext_tot})
-        gnames = ["global_lane_kernel<64, true> (ksw_global2 + traceback, w <= 31, 64 tasks/wave)", "global_lane_kernel<96> + <128> (32 <= w <= 47, 48 <= w <= 63)",
+        gnames = ["global_lane_kernel<64, true, true> (ksw_global2 + traceback, w <= 31, 64 tasks/wave)", "global_lane_kernel<96> + <128> (32 <= w <= 47, 48 <= w <= 63)",
                   "global_kernel (one wave per task: wide bands, long targets)"]
         for b in range(3):
             kernels.append({"kernel": gnames[b], "ms": float(gbin_ms[b]), "launches": n_chunks, "tasks": int((gbin == b).sum()), "single_kernel": b != 1,

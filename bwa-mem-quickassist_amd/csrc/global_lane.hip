@@ -49,7 +49,9 @@ __device__ __forceinline__ int sel3(int mask, int a, int b) { return __builtin_a
 #endif
 
 
-template <int C, bool FAST>
+// SYM: o_del + e_del == o_ins + e_ins (bwa's defaults): m - oe is shared by the E and F updates.  A run-time test of that inside the cell was
+// compiled to a branch per cell.
+template <int C, bool FAST, bool SYM>
 __global__ __launch_bounds__(64, (C <= 64 ? BMH_GL_WAVES64 : C <= 96 ? BMH_GL_WAVES96 : BMH_GL_WAVES128)) void global_lane_kernel(
     const uint8_t *__restrict__ pool, const bmh_glb_task_t *__restrict__ tasks, const uint32_t *__restrict__ order,
     const uint32_t *__restrict__ count, long long n, bmh_glb_result_t *__restrict__ out, uint32_t *__restrict__ cigar_pool,
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(64, (C <= 64 ? BMH_GL_WAVES64 : C <= 96 ? BMH_GL_WA
 							const int h1 = max16(m, e);                     // ksw.c:547-550
 							const int h = max16(h1, f);
 							const int t1 = subk16(m, oe_del), e2 = subk16(e, e_del); // ksw.c:552-556
-							const int t2 = oe_ins == oe_del ? t1 : subk16(m, oe_ins), f2 = subk16(f, e_ins); // ksw.c:557-560
+							const int t2 = SYM ? t1 : subk16(m, oe_ins), f2 = subk16(f, e_ins); // ksw.c:557-560
 #ifdef BMH_GL_PERM_SIGNS // (round 3's first form: four differences, their high bytes gathered pairwise by v_perm)
 							const int x1 = sub16(m, e), x2 = sub16(h1, f), x3 = sub16(t1, e2), x4 = sub16(t2, f2);
 							const int z12 = (int)__builtin_amdgcn_perm((unsigned)x1, (unsigned)x2, 0x0c0c0105u);
@@ -375,21 +377,24 @@ int launch_global_lane(bmh_ctx *ctx, int c, const uint8_t *d_pool, const bmh_glb
 	int rc = ensure(ctx, ctx->d_zslab, slab);
 	if (rc) return rc;
 	const bool fast = ctx->glb_fast != 0; // (A/B knob BMH_GL_FAST: 0 = masked body only)
+	const bool sym = ctx->dev.o_del + ctx->dev.e_del == ctx->dev.o_ins + ctx->dev.e_ins;
 	const size_t lds = (size_t)std::max(c, kStreamRows) * 64; // window staging (C/4 dwords per lane), then one byte per staged row and lane
+#define BMH_LAUNCH_GL2(CC, FF, SS)                                                                                             \
+	hipLaunchKernelGGL((global_lane_kernel<CC, FF, SS>), dim3((unsigned)grid), dim3(64), lds, ctx->stream, d_pool, d_tasks, d_order, \
+	                   d_count, (long long)n, d_res, d_cigar, ctx->dev, (uint32_t *)ctx->d_zslab.p, rows_cap, ctx->d_err)
 #define BMH_LAUNCH_GL(CC)                                                                                                      \
 	do {                                                                                                                       \
-		if (fast)                                                                                                              \
-			hipLaunchKernelGGL((global_lane_kernel<CC, true>), dim3((unsigned)grid), dim3(64), lds, ctx->stream, d_pool, d_tasks, d_order, \
-			                   d_count, (long long)n, d_res, d_cigar, ctx->dev, (uint32_t *)ctx->d_zslab.p, rows_cap, ctx->d_err);     \
-		else                                                                                                                   \
-			hipLaunchKernelGGL((global_lane_kernel<CC, false>), dim3((unsigned)grid), dim3(64), lds, ctx->stream, d_pool, d_tasks, d_order, \
-			                   d_count, (long long)n, d_res, d_cigar, ctx->dev, (uint32_t *)ctx->d_zslab.p, rows_cap, ctx->d_err);    \
+		if (fast && sym) BMH_LAUNCH_GL2(CC, true, true);                                                                       \
+		else if (fast) BMH_LAUNCH_GL2(CC, true, false);                                                                        \
+		else if (sym) BMH_LAUNCH_GL2(CC, false, true);                                                                         \
+		else BMH_LAUNCH_GL2(CC, false, false);                                                                                 \
 	} while (0)
 	if (c == 64) BMH_LAUNCH_GL(64);
 	else if (c == 96) BMH_LAUNCH_GL(96);
 	else if (c == 128) BMH_LAUNCH_GL(128);
 	else return BMH_E_ARG;
 #undef BMH_LAUNCH_GL
+#undef BMH_LAUNCH_GL2
 	BMH_HIP(ctx, hipGetLastError());
 	return BMH_OK;
 }
