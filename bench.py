@@ -744,8 +744,8 @@ def main():
                         "valu_insts_per_launch": insts_per_launch, "valu_per_cell_static": mk.get("valu_per_cell"),
                         "source": "profiles/r03_valu_issue_classes.md (measured classes), profiles/r03_valu_mix.json (this kernel's loop), "
                                   "SQ_INSTS_VALU from " + (traffic_src or "no PMC file for this tree"),
-                        "note": "the launch shares the chip with the other stages' kernels (3 streams); the peak needs >= 4 resident waves per SIMD for the "
-                                "fast class, the kernel's register count allows fewer (DESIGN.md)"}
+                        "note": "the launch shares the chip with the other stages' kernels (3 streams); the class costs hold from 2 resident waves per SIMD on "
+                                "in a stream that is not pure vector code (profiles/r03_valu_pairing.md, DESIGN.md 4.2)"}
             elif mk:
                 valu = {"skipped": f"profiles/r03_valu_mix.json is from kernel sources {mj.get('csrc_sha')}, this tree is {tree_sha} (python tools/make_valu_mix_profile.py)"}
         metric = "aligned reads/sec (150 bp PE vs hg38) at 1/2/4/8 MI355X; SAM bit-exact vs CPU"
