@@ -16,16 +16,16 @@ KERNELS = [  # file, demangled-name pattern, DP cells one trip of the hot loop a
     ("extend_lane.hip", "extend_lane_kernel<64, true, false>", 64),
     ("extend_lane.hip", "extend_lane_kernel<96, true, false>", 96),
     ("extend_lane.hip", "extend_lane_kernel<128, true, false>", 128),
-    ("global_lane.hip", "global_lane_kernel<64, true, true>", 64),
-    ("global_lane.hip", "global_lane_kernel<96, true, true>", 96),
-    ("global_lane.hip", "global_lane_kernel<128, true, true>", 128),
+    ("global_lane.hip", "global_lane_kernel<64, true, true>", 128),   # (the loop holds the masked and the unmasked body of every block: 2 x C cells)
+    ("global_lane.hip", "global_lane_kernel<96, true, true>", 192),
+    ("global_lane.hip", "global_lane_kernel<128, true, true>", 256),
     ("sw_lane.hip", "sw_lane_kernel<80, true, false, false>", 160),
 ]
 out = {"csrc_sha": csrc_sha(ROOT), "clock_GHz": valu_mix.CLOCK_GHZ, "cycles": valu_mix.CYC, "kernels": {}}
 md = ["# Instruction mix of the lane kernels' DP row loops, priced with the measured issue classes (round 3)", "",
       "`python tools/make_valu_mix_profile.py` (static count over the hot loop of the gfx950 assembly; classes and their cost: "
-      "`profiles/r03_valu_issue_classes.md`). A loop that holds two bodies of a block (masked and unmasked) counts both, so the per-cell "
-      "figures of `global_lane_kernel<C, true, true>` are upper bounds.", "",
+      "`profiles/r03_valu_issue_classes.md`, `profiles/r03_valu_pairing.md`). The row loop of `global_lane_kernel<C, true, true>` holds two bodies of every "
+      "block (masked and unmasked), of which a row runs one: its per-cell figures are the mean of the two.", "",
       "| kernel | VALU in loop | fast (2 cyc) | slow (4 cyc) | slow8 | cycles per VALU | mix-weighted issue peak, G wave-instr/s | VALU per cell | issue cycles per cell |",
       "|---|---|---|---|---|---|---|---|---|"]
 for f, pat, cells in KERNELS:
