@@ -16,7 +16,18 @@ from collections import defaultdict
 d = sys.argv[1]
 tj = sys.argv[sys.argv.index("--traffic-json") + 1] if "--traffic-json" in sys.argv else None
 print(f"# rocprofv3 summary of `{os.path.basename(d)}`\n")
-for f in glob.glob(os.path.join(d, "trace", "*", "*kernel_stats.csv")):
+def newest(pattern):
+    """gpurun MERGES a run's files into the local directory, so earlier runs' files (other process ids in their names) may still lie
+    there: per directory only the most recent file counts"""
+    by_dir = {}
+    for f in glob.glob(pattern):
+        k = os.path.dirname(f)
+        if k not in by_dir or os.path.getmtime(f) > os.path.getmtime(by_dir[k]):
+            by_dir[k] = f
+    return sorted(by_dir.values())
+
+
+for f in newest(os.path.join(d, "trace", "*", "*kernel_stats.csv")):
     print("## kernel stats (rocprofv3 --kernel-trace --stats)\n")
     rows = list(csv.DictReader(open(f)))
     print("| kernel | calls | total ns | avg ns | min ns | max ns | % |")
@@ -24,7 +35,7 @@ for f in glob.glob(os.path.join(d, "trace", "*", "*kernel_stats.csv")):
     for r in rows:
         print(f"| {r['Name'][:80]} | {r['Calls']} | {r['TotalDurationNs']} | {float(r['AverageNs']):.0f} | {r['MinNs']} | {r['MaxNs']} | {float(r['Percentage']):.2f} |")
 acc = defaultdict(lambda: defaultdict(lambda: defaultdict(float)))  # kernel -> counter -> dispatch -> value
-for f in sorted(glob.glob(os.path.join(d, "pmc*", "*", "*counter_collection.csv"))):
+for f in newest(os.path.join(d, "pmc*", "*", "*counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         if "bmh" not in r["Kernel_Name"]:
             continue
