@@ -37,7 +37,7 @@ __device__ __forceinline__ int quad_allmin(int v)
 	return v;
 }
 
-template <int LPT>
+template <int LPT, bool SYM>
 __global__ __launch_bounds__(64, 2) void extend_lanex_kernel(const uint8_t *__restrict__ pool,
                                                              const bmh_ext_task_t *__restrict__ tasks,
                                                              const uint32_t *__restrict__ order,
@@ -49,7 +49,11 @@ __global__ __launch_bounds__(64, 2) void extend_lanex_kernel(const uint8_t *__re
 	constexpr int NW = C / 32, NB = C / 8;
 	constexpr int INF = 0x7fff;
 	__shared__ uint2 srow[8]; // srow[t] = the 5 signed score bytes mat[t*5 .. t*5+4]
-	__shared__ uint8_t qsel[128 * 64]; // query code of column p of lane l at [p*64 + l]: one conflict-free ds_read_u8 per cell
+	__shared__ uint32_t qsel4[32 * 64]; // query codes of columns 4v..4v+3 of lane l at [v*64 + l]: the selectors of one v_perm_b32 per four cells
+	// the target, kStreamRows rows at a time, one byte per row at [row][lane]: a global load inside the row loop under an exec mask costs
+	// an s_waitcnt vmcnt(0) -- a memory round trip -- per DP row (extend_lane.hip)
+	constexpr int kStreamRows = 64;
+	__shared__ uint8_t strm[kStreamRows * 64];
 	const int lane = threadIdx.x, role = lane % LPT, c0 = role * C; // this lane owns global columns [c0, c0+C)
 	const int oe_del = P.o_del + P.e_del, oe_ins = P.o_ins + P.e_ins;
 	const int e_del = P.e_del, e_ins = P.e_ins;
@@ -85,11 +89,17 @@ __global__ __launch_bounds__(64, 2) void extend_lanex_kernel(const uint8_t *__re
 
 	// ---- per-lane column state (ksw.c:389-396), the whole query right-aligned in the TOT columns of the quad
 	int HE[C];
-	for (int p = 0; p < C; ++p) {
-		const int j = c0 + p - off;
-		int qb = 4;
-		if (valid && !bad && j >= 0) qb = seq_base(pool, q_off, j, qrev);
-		qsel[p * 64 + lane] = (uint8_t)qb;
+#pragma unroll 2
+	for (int v = 0; v < C / 4; ++v) {
+		int sw = 0;
+#pragma unroll
+		for (int b = 0; b < 4; ++b) {
+			const int j = c0 + 4 * v + b - off;
+			int qb = 4;
+			if (valid && !bad && j >= 0) qb = seq_base(pool, q_off, j, qrev);
+			sw |= qb << (8 * b);
+		}
+		qsel4[v * 64 + lane] = (uint32_t)sw;
 	}
 #pragma unroll
 	for (int p = 0; p < C; ++p) {
@@ -105,12 +115,17 @@ __global__ __launch_bounds__(64, 2) void extend_lanex_kernel(const uint8_t *__re
 		int *p = (int *)(out + idx);
 		p[0] = h0, p[1] = 0, p[2] = 0, p[3] = 0, p[4] = -1, p[5] = 0;
 	}
-	int tnext = alive ? tgt_base(pool, P, t_off, 0, trev, tpac) : 0;
 
 	for (int i = 0; __builtin_amdgcn_ballot_w64(alive) != 0; ++i) { // i is wave-uniform: all tasks started together
-		const int tcur = tnext;
-		tnext = 0;
-		if (alive && i + 1 < tlen) tnext = tgt_base(pool, P, t_off, i + 1, trev, tpac); // consumed one row later
+		if ((i & (kStreamRows - 1)) == 0) { // wave-uniform: target rows [i, i + kStreamRows) of every lane still running
+#pragma unroll 4
+			for (int r = 0; r < kStreamRows; ++r) {
+				int tb_ = 0;
+				if (alive && i + r < tlen) tb_ = tgt_base(pool, P, t_off, i + r, trev, tpac);
+				strm[r * 64 + lane] = (uint8_t)tb_;
+			}
+		}
+		const int tcur = strm[(i & (kStreamRows - 1)) * 64 + lane];
 		const uint2 row = srow[min(tcur, 4)];
 		begp = max(begp, i - w + off);     // ksw.c:418-420
 		endp = min(endp, i + w + 1 + off); // endp <= TOT covers the qlen clamp
@@ -146,23 +161,28 @@ __global__ __launch_bounds__(64, 2) void extend_lanex_kernel(const uint8_t *__re
 			for (int b = 0; b < NB; ++b) {
 				// needed by a lane that is due iff [8b,8b+8) meets [beg,end]  (end itself receives eh[end])
 				if (__builtin_amdgcn_ballot_w64(plb < 8 * b + 8 && ple >= 8 * b) == 0) continue;
+				// the cell in 16-bit instructions (bmh_device.h; extend_lane.hip has the same one): every quantity of the recurrence is >= 0
+				// except M = H(i-1,j-1) + S, which only enters a signed maximum with E >= 0
 #pragma unroll
-				for (int c = 0; c < 8; ++c) {
-					const int p = 8 * b + c;
-					const int actv = (pam[p / 32] << (31 - p % 32)) >> 31;
-					const unsigned sel = qsel[p * 64 + lane];
-					const int sc = (int)(int8_t)__builtin_amdgcn_perm(row.y, row.x, sel);
-					const int e = (int)((unsigned)HE[p] >> 16);
-					const int hh = max((int)(HE[p] & 0xffff) + sc, e);          // ksw.c:430-431
-					const int h = max(hh, f);                                   // ksw.c:432
-					const int en = max(max(e - e_del, h - oe_del), 0) & actv;   // ksw.c:436-439
-					f = max(max(f - e_ins, h - oe_ins), 0) & actv;              // ksw.c:441-444
-					HE[p] = bfx(minev, en << 16 | hprev, HE[p]);                // eh[j] = {H(i,j-1), E(i+1,j)}
-					const int ha = bfx(actv, h, -1);
-					pk = max(pk, ha << 16 | (c0 + p));                          // global column in the key
-					pnz[p / 32] |= (int)(min((unsigned)h, 1u) << (p % 32));
-					hprev = bfx(actv, h, left);
-					if (p == C - 1) phl = ha;
+				for (int q4 = 0; q4 < 2; ++q4) {
+					const int sc4 = (int)__builtin_amdgcn_perm(row.y, row.x, qsel4[(2 * b + q4) * 64 + lane]);
+#pragma unroll
+					for (int c4 = 0; c4 < 4; ++c4) {
+						const int p = 8 * b + 4 * q4 + c4;
+						const int actv = (pam[p / 32] << (31 - p % 32)) >> 31;
+						const int m = c4 == 0 ? add_score<0>(sc4, HE[p]) : c4 == 1 ? add_score<1>(sc4, HE[p]) : c4 == 2 ? add_score<2>(sc4, HE[p]) : add_score<3>(sc4, HE[p]);
+						const int e = (int)((unsigned)HE[p] >> 16);
+						const int h = max16(max16(m, e), f);                              // ksw.c:430-432
+						const int t = subc16(h, oe_del);                                  // max(h - oe_del, 0)
+						const int en = maxu16(subc16(e, e_del), t) & actv;                // ksw.c:436-439
+						f = maxu16(subc16(f, e_ins), SYM ? t : subc16(h, oe_ins)) & actv; // ksw.c:441-444
+						HE[p] = bfx(minev, en << 16 | hprev, HE[p]);                      // eh[j] = {H(i,j-1), E(i+1,j)}
+						const int ha = bfx(actv, h, -1);
+						pk = max(pk, ha << 16 | (c0 + p));                                // global column in the key
+						pnz[p / 32] |= nonzero16(h) << (p % 32);
+						hprev = bfx(actv, h, left);
+						if (p == C - 1) phl = ha;
+					}
 				}
 			}
 			kmax = bfx(minev, pk, kmax), hlast = bfx(minev, phl, hlast);
@@ -226,12 +246,15 @@ int launch_extend_lanex(bmh_ctx *ctx, int lpt, const uint8_t *d_pool, const bmh_
 	long long grid = (n + tpw - 1) / tpw; // n = the dispatcher's upper bound of the bin size; the kernel strides
 	const long long cap = ext_resident_waves(ctx, 2) * ctx->ext_grid_mult;
 	if (grid > cap) grid = cap;
-	if (lpt == 2)
-		hipLaunchKernelGGL(extend_lanex_kernel<2>, dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_pool, d_tasks, d_order, d_count,
-		                   (long long)n, d_res, ctx->dev, ctx->d_err, min_count);
-	else if (lpt == 4)
-		hipLaunchKernelGGL(extend_lanex_kernel<4>, dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_pool, d_tasks, d_order, d_count,
-		                   (long long)n, d_res, ctx->dev, ctx->d_err, min_count);
+	const bool sym = ctx->dev.o_del + ctx->dev.e_del == ctx->dev.o_ins + ctx->dev.e_ins;
+#define BMH_LAUNCH_LANEX(LL, SS)                                                                                        \
+	hipLaunchKernelGGL((extend_lanex_kernel<LL, SS>), dim3((unsigned)grid), dim3(64), 0, ctx->stream, d_pool, d_tasks, d_order, d_count, \
+	                   (long long)n, d_res, ctx->dev, ctx->d_err, min_count)
+	if (lpt == 2 && sym) BMH_LAUNCH_LANEX(2, true);
+	else if (lpt == 2) BMH_LAUNCH_LANEX(2, false);
+	else if (lpt == 4 && sym) BMH_LAUNCH_LANEX(4, true);
+	else if (lpt == 4) BMH_LAUNCH_LANEX(4, false);
+#undef BMH_LAUNCH_LANEX
 	else return BMH_E_ARG;
 	BMH_HIP(ctx, hipGetLastError());
 	return BMH_OK;

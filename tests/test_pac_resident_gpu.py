@@ -144,19 +144,28 @@ def _md_of(words, q, t, rev):
     return mm + gap, bytes(out)
 
 
-def test_region_records_against_oracle_global_and_md():
+@pytest.mark.parametrize("l_pac", [60000, 2_300_000_011], ids=["small", "coordinates past 2^32"])
+def test_region_records_against_oracle_global_and_md(l_pac):
     """bmh_region_cigar_batch record by record: windows of both strands fetched and oriented on the device, three tries per region with
     bands given here, one-try regions, no-gap regions; against the oracle's ksw_global2 on oriented copies made in numpy, the band loop
-    replayed in Python and a Python restatement of bwa.c:134-164.  Then the capacity flags, and the loud error without a reference."""
+    replayed in Python and a Python restatement of bwa.c:134-164.  Then the capacity flags, and the loud error without a reference.
+    Second case: a 2.3 Gbp reference (575 MB of 2-bit codes), so that forward-strand positions pass 2^31 and reverse-strand ones 2^32."""
     from __graft_entry__ import load_package
     pkg = load_package()
     rng = np.random.default_rng(611)
-    l_pac = 60000
-    bases = rng.integers(0, 4, l_pac, dtype=np.uint8)
-    pad = np.concatenate([bases, np.zeros((-l_pac) % 4 + 4, np.uint8)])
-    q4 = pad[: (len(pad) // 4) * 4].reshape(-1, 4)
-    pac = (q4[:, 0] << 6 | q4[:, 1] << 4 | q4[:, 2] << 2 | q4[:, 3]).astype(np.uint8)
-    dbl = np.concatenate([bases, (3 - bases)[::-1]])
+    pac = rng.integers(0, 256, l_pac // 4 + 1, dtype=np.uint8)
+
+    def window(pos, n):
+        """n bases of the doubled coordinate from pos on (bntseq.c:355-376), decoded from the 2-bit array"""
+        if pos >= l_pac:  # reverse strand: complement of the forward strand read backwards
+            f0 = 2 * l_pac - pos - n
+            return (3 - _fwd(f0, n))[::-1]
+        return _fwd(pos, n)
+
+    def _fwd(f0, n):
+        idx = np.arange(f0, f0 + n, dtype=np.int64)
+        return ((pac[idx >> 2] >> ((~idx & 3) << 1).astype(np.uint8)) & 3).astype(np.uint8)
+
     p = kswlib.make_params()
     ctx = _ctx_with({})
     try:
@@ -168,9 +177,9 @@ def test_region_records_against_oracle_global_and_md():
             L = int(rng.integers(30, 260))
             rev = k & 1
             lo, hi = (l_pac, 2 * l_pac) if rev else (0, l_pac)
-            pos = int(rng.integers(lo + 10, hi - L - 40))
+            pos = int(rng.integers(max(lo + 10, hi - 5_000_000), hi - L - 40))  # (near the top of the strand: the largest coordinates)
             tl = L
-            read = dbl[pos:pos + L].copy()
+            read = window(pos, L).copy()
             kind = k % 4
             if kind != 3:  # mismatches, and for kinds 1-2 an indel
                 mut = rng.random(L) < 0.05
@@ -190,7 +199,7 @@ def test_region_records_against_oracle_global_and_md():
             single = k % 5 == 0
             q["truesc"] = INT_MIN if single else ql - int(rng.integers(0, 30))
             oq = read[::-1] if rev else read
-            ot = dbl[pos:pos + tl][::-1] if rev else dbl[pos:pos + tl]
+            ot = window(pos, tl)[::-1] if rev else window(pos, tl)
             task = [-1, -1, -1]
             if not (kind in (0, 3) and k % 8 < 4):  # (mismatch-only regions: half of them as the no-gap case)
                 prev = -1
