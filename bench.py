@@ -201,13 +201,15 @@ class HostFeed:
     host/reg2cigar_batch.c through the preload shim): per chunk the READS and the task records up, the finished regions, global scores,
     CIGAR words (16 words of room per task, as host/sam_post.c hands it out) and rescue results down.  The reference windows of the
     seed records do not travel: they stand for reference bases, which the shim keeps resident in HBM (bmh_ctx_set_pac; here: the
-    windows region of each chunk's pool, uploaded once before the timed region).  The global tasks' target bytes DO travel -- the
-    CIGAR driver still ships decoded windows.  Everything starts in PINNED host memory; each chunk's upload rides a copy
+    windows region of each chunk's pool, uploaded once before the timed region).  Nor do the global tasks' TARGET bytes: they are
+    reference windows too, which the library's region record (bmh_region_cigar_batch) fetches from the resident
+    reference on the device -- of a global task its query bytes and its 32-byte record travel (--feed-global-windows ships the targets as
+    well, as the CIGAR driver did before the region record).  Everything starts in PINNED host memory; each chunk's upload rides a copy
     stream one chunk ahead of the compute streams, the kernels run exactly as in the resident step, results come back on a third
     stream -- all inside the timed region.  Chunks are numbered globally, so the pipeline keeps running across step boundaries."""
     CIGAR_WORDS = 16
 
-    def __init__(self, torch, dev, pkg, tg, host, host_sw, ctxs_of, streams_of):
+    def __init__(self, torch, dev, pkg, tg, host, host_sw, ctxs_of, streams_of, ship_global_windows=False):
         self.torch, self.dev = torch, dev
         self.cx_exts, self.cx_glb, self.cx_sw = ctxs_of
         self.s_exts, self.s_glb, self.s_sw = streams_of
@@ -219,22 +221,26 @@ class HostFeed:
             sp, st, rb = tg.split_reads_windows(pool, seeds)  # [all reads | all windows], offsets rewritten
             d_pool = dz(len(sp))
             d_pool[rb:].copy_(torch.from_numpy(sp[rb:]))  # the windows = the resident reference: uploaded once, outside the timed region
-            gt = gtasks.copy()
+            gp, gt, qb = tg.split_queries_targets(gpool, gtasks)  # [all queries | all targets], offsets rewritten
+            if ship_global_windows:
+                qb = len(gp)
+            d_gpool = dz(len(gp))
+            d_gpool[qb:].copy_(torch.from_numpy(gp[qb:]))  # the targets = reference windows: resident, like the seeds' windows
             gt["cigar_off"] = np.arange(len(gt), dtype=np.uint32) * HostFeed.CIGAR_WORDS
             gt["cigar_cap"] = HostFeed.CIGAR_WORDS
             gw = len(gt) * HostFeed.CIGAR_WORDS
-            self.chunks.append({"reads": pin(sp[:rb]), "d_pool": d_pool, "in": [pin(st), pin(gpool), pin(gt)], "n": len(st), "ng": len(gt),
-                                "window_bytes": len(sp) - rb,
+            self.chunks.append({"reads": pin(sp[:rb]), "d_pool": d_pool, "gq": pin(gp[:qb]), "d_gpool": d_gpool, "in": [pin(st), pin(gt)],
+                                "n": len(st), "ng": len(gt), "window_bytes": len(sp) - rb + len(gp) - qb,
                                 "out": [torch.empty(len(st) * pkg.SEED_RES.itemsize, dtype=torch.uint8).pin_memory(),
                                         torch.empty(len(gt) * pkg.GLB_RES.itemsize, dtype=torch.uint8).pin_memory(),
                                         torch.empty((gw + 8) * 4, dtype=torch.uint8).pin_memory()]})
         self.sw = [{"in": [pin(sp_), pin(st_)], "n": len(st_), "out": torch.empty(len(st_) * pkg.SW_RES.itemsize, dtype=torch.uint8).pin_memory()}
                    for sp_, st_ in host_sw]
-        cap_in = [max(c["in"][i].numel() for c in self.chunks) for i in range(3)]
+        cap_in = [max(c["in"][i].numel() for c in self.chunks) for i in range(2)]
         cap_out = [max(c["out"][i].numel() for c in self.chunks) for i in range(3)]
         self.slots = [{"in": [dz(b) for b in cap_in], "out": [dz(b) for b in cap_out]} for _ in range(2)]
         self.sw_slot = {"in": [dz(max(b["in"][i].numel() for b in self.sw)) for i in range(2)], "out": dz(max(b["out"].numel() for b in self.sw))}
-        self.h2d_bytes = sum(c["reads"].numel() + sum(t.numel() for t in c["in"]) for c in self.chunks) + sum(t.numel() for b in self.sw for t in b["in"])
+        self.h2d_bytes = sum(c["reads"].numel() + c["gq"].numel() + sum(t.numel() for t in c["in"]) for c in self.chunks) + sum(t.numel() for b in self.sw for t in b["in"])
         self.d2h_bytes = sum(t.numel() for c in self.chunks for t in c["out"]) + sum(b["out"].numel() for b in self.sw)
         self.resident_window_bytes = sum(c["window_bytes"] for c in self.chunks)
         self.g = 0            # global chunk number
@@ -258,11 +264,12 @@ class HostFeed:
             if timed:
                 e0 = torch.cuda.Event(enable_timing=True); e0.record(self.h2d)
             c["d_pool"][: c["reads"].numel()].copy_(c["reads"], non_blocking=True)
+            c["d_gpool"][: c["gq"].numel()].copy_(c["gq"], non_blocking=True)
             for src, dst in zip(c["in"], slot["in"]):
                 dst[: src.numel()].copy_(src, non_blocking=True)
             if timed:
                 e1 = torch.cuda.Event(enable_timing=True); e1.record(self.h2d)
-                self.copy_events.append((e0, e1, c["reads"].numel() + sum(t.numel() for t in c["in"])))
+                self.copy_events.append((e0, e1, c["reads"].numel() + c["gq"].numel() + sum(t.numel() for t in c["in"])))
         ev = torch.cuda.Event(); ev.record(self.h2d)
         self.up_done[g] = ev
 
@@ -282,7 +289,7 @@ class HostFeed:
             if back is not None:
                 s.wait_event(back)
         cx_ext.seedext_batch_device(c["d_pool"].data_ptr(), slot["in"][0].data_ptr(), c["n"], slot["out"][0].data_ptr())
-        self.cx_glb.global_batch_device(slot["in"][1].data_ptr(), slot["in"][2].data_ptr(), c["ng"], slot["out"][1].data_ptr(), slot["out"][2].data_ptr())
+        self.cx_glb.global_batch_device(c["d_gpool"].data_ptr(), slot["in"][1].data_ptr(), c["ng"], slot["out"][1].data_ptr(), slot["out"][2].data_ptr())
         e_ext, e_glb = torch.cuda.Event(), torch.cuda.Event()
         e_ext.record(s_ext); e_glb.record(self.s_glb)
         self.comp_done[g] = (e_ext, e_glb)
@@ -349,6 +356,9 @@ def main():
                     help="resident: inputs in HBM when the timed region starts (`value`, the contract's definition); host: also time the same steps "
                          "with every chunk uploaded from pinned host memory one chunk ahead of compute and every result downloaded "
                          "(`value_streamed`); both (default): the two timed regions one after the other")
+    ap.add_argument("--feed-global-windows", action="store_true",
+                    help="host-fed steps: ship the global tasks' target windows as well (the CIGAR driver before the region record); default: they stay "
+                         "resident like the seeds' windows")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="rehearsal on a box with fewer GPUs than ranks: rank r uses device r %% (visible devices), the barrier and the report "
                          "go over gloo (RCCL refuses two ranks on one device).  Never for a reported number.")
@@ -522,7 +532,7 @@ def main():
     if args.feed in ("host", "both"):
         note(f"timed: {rank_ms:.1f} ms per step resident; pinning host buffers for the host-fed steps")
         t0 = time.time()
-        feed = HostFeed(torch, dev, pkg, tg, host, host_sw, (cx_exts, cx_glb, cx_sw), (ext_streams, streams[1 % len(streams)], streams[2 % len(streams)]))
+        feed = HostFeed(torch, dev, pkg, tg, host, host_sw, (cx_exts, cx_glb, cx_sw), (ext_streams, streams[1 % len(streams)], streams[2 % len(streams)]), ship_global_windows=args.feed_global_windows)
         pin_s = time.time() - t0
         for _ in range(max(1, args.warmup)):
             feed.step()
@@ -546,7 +556,9 @@ def main():
                     "h2d_GBps_copy_stream": up_bytes / (up_ms * 1e-3) / 1e9 if up_ms > 0 else None,
                     "pcie_GBps_over_the_step": (feed.h2d_bytes + feed.d2h_bytes) / (rank_ms_s * 1e-3) / 1e9,
                     "pin_s": pin_s,
-                    "what": "reads + task records (+ the global tasks' query and target bytes) in pinned host memory, each chunk uploaded one chunk "
+                    "global_windows_shipped": bool(args.feed_global_windows),
+                    "what": "reads + task records (+ the global tasks' query bytes; their target windows stay resident like the seeds', as with the "
+                            "library's region record -- unless --feed-global-windows) in pinned host memory, each chunk uploaded one chunk "
                             "ahead of compute (copy stream), kernels as in the resident step, finished regions / global scores / CIGAR words "
                             "(16 words of room per task) / rescue results downloaded to pinned host memory (third stream), all inside the timed "
                             "region; the seed records' reference windows are resident in HBM, as the reference is in the preload shim"}

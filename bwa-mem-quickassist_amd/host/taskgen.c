@@ -331,3 +331,27 @@ size_t bmh_taskgen_split(const uint8_t *pool_in, bmh_seed_task_t *tasks, int64_t
 	if (reads_bytes) *reads_bytes = R;
 	return w + 16;
 }
+
+/* The same for ksw_global2 tasks: pool_out = [all queries | all targets].  The targets stand for reference windows, which the region record
+ * (bmh_region_cigar_batch) fetches from the resident 2-bit reference on the device, so a host-fed measurement ships only the queries.
+ * *query_bytes = size of the queries region (a multiple of 64).  Returns the bytes used in pool_out, 0 if it is too small. */
+size_t bmh_taskgen_split_glb(const uint8_t *pool_in, bmh_glb_task_t *tasks, int64_t n, uint8_t *pool_out, size_t out_cap, size_t *query_bytes)
+{
+	size_t Q = 0, T = 0, q = 0, w;
+	int64_t k;
+	for (k = 0; k < n; ++k) Q += (size_t)tasks[k].qlen, T += (size_t)tasks[k].tlen;
+	Q = (Q + 63) & ~(size_t)63;
+	if (Q + T + 16 > out_cap) return 0;
+	w = Q;
+	for (k = 0; k < n; ++k) {
+		bmh_glb_task_t *t = &tasks[k];
+		memcpy(pool_out + q, pool_in + t->q_off, (size_t)t->qlen);
+		memcpy(pool_out + w, pool_in + t->t_off, (size_t)t->tlen);
+		t->q_off = q, t->t_off = w;
+		q += (size_t)t->qlen, w += (size_t)t->tlen;
+	}
+	memset(pool_out + q, 0, Q - q);
+	memset(pool_out + w, 0, 16);
+	if (query_bytes) *query_bytes = Q;
+	return w + 16;
+}

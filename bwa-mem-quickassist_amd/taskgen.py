@@ -100,6 +100,22 @@ def split_reads_windows(pool, seeds):
     return out[:used], t, int(rb.value)
 
 
+def split_queries_targets(gpool, gtasks):
+    """(pool', tasks', query_bytes): the same ksw_global2 tasks over a pool laid out [all queries | all targets] -- the targets stand for
+    reference windows resident in HBM (the region record fetches them there), only pool'[:query_bytes] travels per batch when host-fed."""
+    from . import GLB_TASK
+    L = _load()
+    L.bmh_taskgen_split_glb.restype = C.c_size_t
+    t = np.ascontiguousarray(gtasks, dtype=GLB_TASK).copy()
+    out = np.empty(len(gpool) + 256, dtype=np.uint8)
+    qb = C.c_size_t(0)
+    used = L.bmh_taskgen_split_glb(gpool.ctypes.data_as(C.c_void_p), t.ctypes.data_as(C.c_void_p), C.c_int64(len(t)),
+                                   out.ctypes.data_as(C.c_void_p), C.c_size_t(out.nbytes), C.byref(qb))
+    if not used:
+        raise RuntimeError("split capacity too small")
+    return out[:used], t, int(qb.value)
+
+
 def generate_global(n_reads, workload="150bp", seed=11, wspread=32):
     """Returns (pool, tasks GLB_TASK[], cigar_words) -- one banded global alignment per simulated read."""
     from . import GLB_TASK
