@@ -260,6 +260,17 @@ def test_region_records_against_oracle_global_and_md(l_pac):
             assert int(r["flags"]) == 0 and int(r["NM"]) == nm and int(r["md_len"]) == len(mds), (k, q, r, mds)
             assert np.array_equal(cig[k, :len(words)], words) and bytes(md[k, :len(mds)]) == mds
         assert min(seen.values()) >= 10, seen
+        # arguments that would make a kernel read outside its buffers are refused on the host, loudly
+        for field, value in (("q_src", len(rpool)), ("o_off", len(opool)), ("rb", 2 * l_pac - 5), ("rb", l_pac - 7), ("task", [len(tasks), -1, -1])):
+            bad = reqs.copy()
+            k = 1 if field != "task" else int(np.nonzero(reqs["task"][:, 0] >= 0)[0][0])
+            bad[field][k] = value
+            with pytest.raises(pkg.BmhError):
+                ctx.region_cigar_batch(rpool, len(opool), bad, tasks, slot + 4)
+        bad_t = tasks.copy()
+        bad_t["t_off"][0] = len(opool)
+        with pytest.raises(pkg.BmhError):
+            ctx.region_cigar_batch(rpool, len(opool), reqs, bad_t, slot + 4)
         # capacities: 2 CIGAR words / 6 MD bytes per region -- what does not fit is flagged, the rest is as before
         res2, cig2, md2 = ctx.region_cigar_batch(rpool, len(opool), reqs, tasks, slot + 4, cig_cap=2, md_cap=6)
         cut = {1: 0, 2: 0, 0: 0}
