@@ -260,6 +260,13 @@ def test_region_records_against_oracle_global_and_md(l_pac):
             assert int(r["flags"]) == 0 and int(r["NM"]) == nm and int(r["md_len"]) == len(mds), (k, q, r, mds)
             assert np.array_equal(cig[k, :len(words)], words) and bytes(md[k, :len(mds)]) == mds
         assert min(seen.values()) >= 10, seen
+        # a batch of no-gap regions only (no ksw_global2 task at all), and an empty batch
+        nd = np.nonzero(reqs["task"][:, 0] < 0)[0]
+        r3, c3, m3 = ctx.region_cigar_batch(rpool, len(opool), reqs[nd], np.zeros(0, pkg.GLB_TASK), 4)
+        assert np.array_equal(r3, res[nd]) and np.array_equal(c3[:, 0], cig[nd, 0])
+        assert all(bytes(m3[j, :int(r3[j]['md_len'])]) == bytes(md[k, :int(res[k]['md_len'])]) for j, k in enumerate(nd))  # (bytes past md_len: unspecified)
+        r4, _, _ = ctx.region_cigar_batch(rpool, len(opool), reqs[:0], tasks, slot + 4)
+        assert len(r4) == 0
         # arguments that would make a kernel read outside its buffers are refused on the host, loudly
         for field, value in (("q_src", len(rpool)), ("o_off", len(opool)), ("rb", 2 * l_pac - 5), ("rb", l_pac - 7), ("task", [len(tasks), -1, -1])):
             bad = reqs.copy()
