@@ -362,7 +362,7 @@ typedef struct bmh_region_res { /* 24 bytes */
 	int32_t md_len;
 	uint32_t flags; /* BMH_REGION_* */
 } bmh_region_res_t;
-/* readpool: the query windows; opool_bytes: size of the oriented pool the o_off / q_off / t_off fields address.  BMH_E_ARG without a
+/* Bytes of a region's MD slot past md_len are unspecified.  readpool: the query windows; opool_bytes: size of the oriented pool the o_off / q_off / t_off fields address.  BMH_E_ARG without a
  * resident reference or with offsets outside the pools. */
 int bmh_region_cigar_batch(bmh_ctx_t *ctx, const uint8_t *readpool, size_t readpool_bytes, size_t opool_bytes,
                            const bmh_region_req_t *reqs, int64_t n_req, const bmh_glb_task_t *tasks, int64_t n_tasks,
