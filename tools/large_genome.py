@@ -19,6 +19,20 @@ reads = int(sys.argv[2]) if len(sys.argv) > 2 else 800_000
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 ncores, note = bench.host_cores()
 t0 = time.time()
+
+
+def _heartbeat():  # the index build is silent for minutes at a time ("Construct SA from BWT and Occ"): keep a file under gpurun_out/ moving
+    import threading
+
+    def beat():
+        while True:
+            time.sleep(45)
+            with open(os.path.join(ROOT, "gpurun_out", "large_genome_heartbeat.log"), "a") as f:
+                f.write(f"{time.time() - t0:.0f} s\n")
+    threading.Thread(target=beat, daemon=True).start()
+
+
+_heartbeat()
 r = bench.pipeline_baseline(reads, genome, ncores, batch=32768, index_log=os.path.join(ROOT, "gpurun_out", "large_genome_index.log"))
 r["total_s"] = time.time() - t0
 r["cores_note"] = note
