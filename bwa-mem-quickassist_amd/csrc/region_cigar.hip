@@ -87,31 +87,40 @@ __global__ __launch_bounds__(64) void region_finish_kernel(const uint8_t *__rest
 		}
 		for (int i = 0; i < r.n_cigar; ++i) cg[i] = tcig[ft.cigar_off + i];
 	}
-	// NM and MD, bwa.c:134-164
+	// NM and MD, bwa.c:134-164: walk the CIGAR over the oriented copies; `run` = matches since the last MD token
 	MdOut md{md_out + (size_t)k * md_cap, 0, md_cap};
-	const char *b2c = rev ? "TGCAN" : "ACGTN";
-	int x = 0, y = 0, u = 0, n_mm = 0, n_gap = 0;
+	const char *letter = rev ? "TGCAN" : "ACGTN";
+	int qpos = 0, tpos = 0, run = 0, mismatches = 0, gap_bases = 0;
 	for (int c = 0; c < r.n_cigar; ++c) {
 		const int op = (int)(cg[c] & 0xf), len = (int)(cg[c] >> 4);
-		if (op == 0) {
+		switch (op) {
+		case 0: // M: a mismatch closes the run and names the reference base
 			for (int i = 0; i < len; ++i) {
-				if (q[x + i] != t[y + i]) {
-					md.num(u), md.c(b2c[t[y + i]]);
-					++n_mm, u = 0;
-				} else ++u;
+				if (q[qpos + i] == t[tpos + i]) {
+					++run;
+					continue;
+				}
+				md.num(run), md.c(letter[t[tpos + i]]);
+				++mismatches, run = 0;
 			}
-			x += len, y += len;
-		} else if (op == 2) {
+			qpos += len, tpos += len;
+			break;
+		case 2: // D: "^" + the deleted reference bases, unless it is the first or the last operation
 			if (c > 0 && c < r.n_cigar - 1) {
-				md.num(u), md.c('^');
-				for (int i = 0; i < len; ++i) md.c(b2c[t[y + i]]);
-				u = 0, n_gap += len;
+				md.num(run), md.c('^');
+				for (int i = 0; i < len; ++i) md.c(letter[t[tpos + i]]);
+				run = 0, gap_bases += len;
 			}
-			y += len;
-		} else if (op == 1) x += len, n_gap += len;
+			tpos += len;
+			break;
+		case 1: // I
+			qpos += len, gap_bases += len;
+			break;
+		default: break;
+		}
 	}
-	md.num(u);
-	r.NM = n_mm + n_gap, r.md_len = md.l;
+	md.num(run);
+	r.NM = mismatches + gap_bases, r.md_len = md.l;
 	if (md.l > md_cap) r.flags |= BMH_REGION_MD_CUT;
 	out[k] = r;
 }

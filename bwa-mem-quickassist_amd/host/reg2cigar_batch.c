@@ -77,37 +77,44 @@ static void put_num(char *s, size_t *l, int c) /* kputw, kstring.h:62-77, c >= 0
 	while (n) s[(*l)++] = buf[--n];
 }
 
-/* bwa.c:134-164; md must have room for 3*(ql+tl)+16 bytes.  Returns NM, *md_len without the NUL. */
+/* bwa.c:134-164 on oriented copies; md must have room for 3*(ql+tl)+16 bytes.  Returns NM, *md_len without the NUL.
+ * `run` = matches since the last MD token. */
 static int nm_md(int n_cigar, const uint32_t *cigar, const uint8_t *q, const uint8_t *t, int rev, char *md, size_t *md_len)
 {
-	const char *int2base = rev ? "TGCAN" : "ACGTN";
-	int k, i, x = 0, y = 0, u = 0, n_mm = 0, n_gap = 0;
+	const char *letter = rev ? "TGCAN" : "ACGTN";
+	int c, i, qpos = 0, tpos = 0, run = 0, mismatches = 0, gap_bases = 0;
 	size_t l = 0;
-	for (k = 0; k < n_cigar; ++k) {
-		const int op = (int)(cigar[k] & 0xf), len = (int)(cigar[k] >> 4);
-		if (op == 0) {
+	for (c = 0; c < n_cigar; ++c) {
+		const int op = (int)(cigar[c] & 0xf), len = (int)(cigar[c] >> 4);
+		switch (op) {
+		case 0: /* M: a mismatch closes the run and names the reference base */
 			for (i = 0; i < len; ++i) {
-				if (q[x + i] != t[y + i]) {
-					put_num(md, &l, u);
-					md[l++] = int2base[t[y + i]];
-					++n_mm, u = 0;
-				} else ++u;
+				if (q[qpos + i] == t[tpos + i]) { ++run; continue; }
+				put_num(md, &l, run);
+				md[l++] = letter[t[tpos + i]];
+				++mismatches, run = 0;
 			}
-			x += len, y += len;
-		} else if (op == 2) {
-			if (k > 0 && k < n_cigar - 1) {
-				put_num(md, &l, u);
+			qpos += len, tpos += len;
+			break;
+		case 2: /* D: "^" + the deleted reference bases, unless it is the first or the last operation */
+			if (c > 0 && c < n_cigar - 1) {
+				put_num(md, &l, run);
 				md[l++] = '^';
-				for (i = 0; i < len; ++i) md[l++] = int2base[t[y + i]];
-				u = 0, n_gap += len;
+				for (i = 0; i < len; ++i) md[l++] = letter[t[tpos + i]];
+				run = 0, gap_bases += len;
 			}
-			y += len;
-		} else if (op == 1) x += len, n_gap += len;
+			tpos += len;
+			break;
+		case 1: /* I */
+			qpos += len, gap_bases += len;
+			break;
+		default: break;
+		}
 	}
-	put_num(md, &l, u);
+	put_num(md, &l, run);
 	md[l] = 0;
 	*md_len = l;
-	return n_mm + n_gap;
+	return mismatches + gap_bases;
 }
 
 static int infer_bw(int l1, int l2, int score, int a, int q, int r) /* bwamem.c:884-891 */
